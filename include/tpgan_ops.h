@@ -1,0 +1,107 @@
+/*
+ * tpgan_ops.h -- C-ABI of libtpgan_hip.so: the MI355X (gfx950) neighbourhood
+ * ops under TPU-GAN's generator, discriminators and losses.
+ *
+ * The reference (zijieli-Jlee/Temporal-Pointcloud-Upsampling-GAN) is pure
+ * Python and never binds a C symbol itself: it calls four third-party CUDA
+ * extensions through their Python APIs.  Each entry point below is what those
+ * Python APIs bind underneath, restated as a plain C function; the comment on
+ * each one cites the reference call site(s) it serves.  The ctypes binding the
+ * reference side would add is shown in INTEGRATION.md and implemented in
+ * temporal-pointcloud-upsampling-gan_amd/_lib.py.
+ *
+ * Conventions
+ *   - all pointers are DEVICE pointers (HBM), row-major contiguous, fp32 /
+ *     int32 / int64 as named; the caller owns every buffer, the library never
+ *     allocates, never synchronises and holds no state;
+ *   - `stream` is a hipStream_t passed as void* (NULL = default stream);
+ *   - returns 0 on success, <0 on error (tpg_status); never throws;
+ *   - canonical arithmetic: sqdist(a,b) = sum_d (a_d-b_d)^2 accumulated in d
+ *     order in fp32 without FMA; neighbour order ascending (dist, idx).
+ */
+#ifndef TPGAN_OPS_H
+#define TPGAN_OPS_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef enum {
+    TPG_OK = 0,
+    TPG_ERR_ARG = -1,         /* bad shape / null pointer / size out of range   */
+    TPG_ERR_LAUNCH = -2,      /* hipGetLastError() != hipSuccess after launch   */
+    TPG_ERR_UNSUPPORTED = -3  /* e.g. K > TPG_MAX_K                             */
+} tpg_status;
+
+#define TPG_MAX_K 64 /* neighbours per query held one-per-lane in a wave64 */
+
+/* library / device identification; safe to call without a GPU */
+const char *tpg_version(void);
+const char *tpg_target_arch(void); /* "gfx950" */
+
+/* K nearest neighbours in D-dim space, optional radius cut.
+ * Replaces pytorch3d.ops.knn_points -- gcn_lib/pointnet/gcn.py:16-21,38,258;
+ * discriminator.py:15-20,33-38 -- and frnn.frnn_grid_points --
+ * discriminator.py:27-32; loss.py:105,142,229,256-265;
+ * gcn_lib/interpolation.py:20,33.
+ * p1 (B,P1,D), p2 (B,P2,D); len1/len2 (B) int64 or NULL (= full).
+ * r2 < 0: plain kNN, missing slots dist 0 / idx 0.
+ * r2 >= 0: only d < r2 (strict); missing slots dist -1 / idx -1.
+ * dist (B,P1,K) f32, idx (B,P1,K) i64, sorted ascending (dist, idx). */
+int tpg_knn_f32(const float *p1, const float *p2, const int64_t *len1,
+                const int64_t *len2, int B, int P1, int P2, int D, int K,
+                float r2, float *dist, int64_t *idx, void *stream);
+
+/* Chamfer nearest-neighbour search in both directions (D = 3).
+ * Replaces chamferdist.ChamferDistance.forward -- loss.py:125-127,176-181.
+ * src (B,N,3), tgt (B,M,3) -> d1,i1 (B,N), d2,i2 (B,M). */
+int tpg_chamfer_fwd_f32(const float *src, const float *tgt, int B, int N, int M,
+                        float *d1, int64_t *i1, float *d2, int64_t *i2,
+                        void *stream);
+/* gsrc (B,N,3) / gtgt (B,M,3) are overwritten (zeroed inside). */
+int tpg_chamfer_bwd_f32(const float *src, const float *tgt, int B, int N, int M,
+                        const int64_t *i1, const int64_t *i2, const float *g1,
+                        const float *g2, float *gsrc, float *gtgt, void *stream);
+
+/* Furthest point sampling.  Replaces pointnet2_utils.furthest_point_sample --
+ * discriminator.py:114.  xyz (B,N,3) -> idx (B,m) int32; temp (B,N) scratch. */
+int tpg_fps_f32(const float *xyz, int B, int N, int m, float *temp, int32_t *idx,
+                void *stream);
+
+/* gather_operation fwd/bwd -- discriminator.py:131-137.
+ * feat (B,C,N), idx (B,S) -> out (B,C,S); bwd overwrites gfeat (B,C,N). */
+int tpg_gather_fwd_f32(const float *feat, const int32_t *idx, int B, int C, int N,
+                       int S, float *out, void *stream);
+int tpg_gather_bwd_f32(const float *gout, const int32_t *idx, int B, int C, int N,
+                       int S, float *gfeat, void *stream);
+
+/* ball_query -- inside pointnet2_utils.QueryAndGroup, discriminator.py:190.
+ * xyz (B,N,3), new_xyz (B,S,3) -> idx (B,S,nsample) int32. */
+int tpg_ball_query_f32(const float *xyz, const float *new_xyz, int B, int N, int S,
+                       float radius, int nsample, int32_t *idx, void *stream);
+
+/* grouping_operation fwd/bwd -- gcn_lib/pointnet/gcn.py:207,261;
+ * discriminator.py:270,273; 2x per QueryAndGroup.
+ * feat (B,C,N), idx (B,S,K) -> out (B,C,S,K); bwd overwrites gfeat (B,C,N). */
+int tpg_group_fwd_f32(const float *feat, const int32_t *idx, int B, int C, int N,
+                      int S, int K, float *out, void *stream);
+int tpg_group_bwd_f32(const float *gout, const int32_t *idx, int B, int C, int N,
+                      int S, int K, float *gfeat, void *stream);
+
+/* three_nn / three_interpolate -- pointnet2_utils API completeness (no call
+ * site in the reference).  dist2 holds SQUARED distances. */
+int tpg_three_nn_f32(const float *unknown, const float *known, int B, int n, int m,
+                     float *dist2, int32_t *idx, void *stream);
+int tpg_three_interp_fwd_f32(const float *feat, const int32_t *idx, const float *w,
+                             int B, int C, int m, int n, float *out, void *stream);
+int tpg_three_interp_bwd_f32(const float *gout, const int32_t *idx, const float *w,
+                             int B, int C, int m, int n, float *gfeat,
+                             void *stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* TPGAN_OPS_H */

@@ -1,0 +1,168 @@
+"""numpy front-end of libtpgref.so (the CPU restatement).  TEST INFRASTRUCTURE ONLY.
+
+Every function takes/returns numpy arrays with the layouts of include/tpgan_ops.h.
+"""
+import ctypes as C
+
+import numpy as np
+
+from . import build
+
+_lib = None
+
+_F = C.POINTER(C.c_float)
+_I32 = C.POINTER(C.c_int32)
+_I64 = C.POINTER(C.c_int64)
+
+
+def lib():
+    global _lib
+    if _lib is None:
+        _lib = C.CDLL(build())
+    return _lib
+
+
+def _f(a):
+    return a.ctypes.data_as(_F)
+
+
+def _i32(a):
+    return a.ctypes.data_as(_I32)
+
+
+def _i64(a):
+    return None if a is None else a.ctypes.data_as(_I64)
+
+
+def _c(a, dt):
+    return np.ascontiguousarray(a, dtype=dt)
+
+
+def _chk(rc, name):
+    if rc != 0:
+        raise RuntimeError(f"oracle {name} failed with status {rc}")
+
+
+def radius_sq(r):
+    """r (python float) -> fp32 r*r exactly as the product's host code does."""
+    r32 = np.float32(r)
+    return float(np.float32(r32 * r32))
+
+
+def knn(p1, p2, K, lengths1=None, lengths2=None, r=None):
+    p1, p2 = _c(p1, np.float32), _c(p2, np.float32)
+    B, P1, D = p1.shape
+    P2 = p2.shape[1]
+    l1 = None if lengths1 is None else _c(lengths1, np.int64)
+    l2 = None if lengths2 is None else _c(lengths2, np.int64)
+    dist = np.empty((B, P1, K), np.float32)
+    idx = np.empty((B, P1, K), np.int64)
+    r2 = -1.0 if r is None else radius_sq(r)
+    _chk(lib().tpgref_knn_f32(_f(p1), _f(p2), _i64(l1), _i64(l2), B, P1, P2, D, K,
+                              C.c_float(r2), _f(dist), _i64(idx)), "knn")
+    return dist, idx
+
+
+def chamfer_fwd(src, tgt):
+    src, tgt = _c(src, np.float32), _c(tgt, np.float32)
+    B, N, _ = src.shape
+    M = tgt.shape[1]
+    d1, i1 = np.empty((B, N), np.float32), np.empty((B, N), np.int64)
+    d2, i2 = np.empty((B, M), np.float32), np.empty((B, M), np.int64)
+    _chk(lib().tpgref_chamfer_fwd_f32(_f(src), _f(tgt), B, N, M, _f(d1), _i64(i1),
+                                      _f(d2), _i64(i2)), "chamfer_fwd")
+    return d1, i1, d2, i2
+
+
+def chamfer_bwd(src, tgt, i1, i2, g1, g2):
+    src, tgt = _c(src, np.float32), _c(tgt, np.float32)
+    i1, i2 = _c(i1, np.int64), _c(i2, np.int64)
+    g1, g2 = _c(g1, np.float32), _c(g2, np.float32)
+    B, N, _ = src.shape
+    M = tgt.shape[1]
+    gs, gt = np.empty_like(src), np.empty_like(tgt)
+    _chk(lib().tpgref_chamfer_bwd_f32(_f(src), _f(tgt), B, N, M, _i64(i1), _i64(i2),
+                                      _f(g1), _f(g2), _f(gs), _f(gt)), "chamfer_bwd")
+    return gs, gt
+
+
+def fps(xyz, m):
+    xyz = _c(xyz, np.float32)
+    B, N, _ = xyz.shape
+    temp = np.empty((B, N), np.float32)
+    idx = np.empty((B, m), np.int32)
+    _chk(lib().tpgref_fps_f32(_f(xyz), B, N, m, _f(temp), _i32(idx)), "fps")
+    return idx
+
+
+def gather_fwd(feat, idx):
+    feat, idx = _c(feat, np.float32), _c(idx, np.int32)
+    B, Cc, N = feat.shape
+    S = idx.shape[1]
+    out = np.empty((B, Cc, S), np.float32)
+    _chk(lib().tpgref_gather_fwd_f32(_f(feat), _i32(idx), B, Cc, N, S, _f(out)), "gather_fwd")
+    return out
+
+
+def gather_bwd(gout, idx, N):
+    gout, idx = _c(gout, np.float32), _c(idx, np.int32)
+    B, Cc, S = gout.shape
+    g = np.empty((B, Cc, N), np.float32)
+    _chk(lib().tpgref_gather_bwd_f32(_f(gout), _i32(idx), B, Cc, N, S, _f(g)), "gather_bwd")
+    return g
+
+
+def ball_query(radius, nsample, xyz, new_xyz):
+    xyz, new_xyz = _c(xyz, np.float32), _c(new_xyz, np.float32)
+    B, N, _ = xyz.shape
+    S = new_xyz.shape[1]
+    idx = np.empty((B, S, nsample), np.int32)
+    _chk(lib().tpgref_ball_query_f32(_f(xyz), _f(new_xyz), B, N, S, C.c_float(radius),
+                                     nsample, _i32(idx)), "ball_query")
+    return idx
+
+
+def group_fwd(feat, idx):
+    feat, idx = _c(feat, np.float32), _c(idx, np.int32)
+    B, Cc, N = feat.shape
+    _, S, K = idx.shape
+    out = np.empty((B, Cc, S, K), np.float32)
+    _chk(lib().tpgref_group_fwd_f32(_f(feat), _i32(idx), B, Cc, N, S, K, _f(out)), "group_fwd")
+    return out
+
+
+def group_bwd(gout, idx, N):
+    gout, idx = _c(gout, np.float32), _c(idx, np.int32)
+    B, Cc, S, K = gout.shape
+    g = np.empty((B, Cc, N), np.float32)
+    _chk(lib().tpgref_group_bwd_f32(_f(gout), _i32(idx), B, Cc, N, S, K, _f(g)), "group_bwd")
+    return g
+
+
+def three_nn(unknown, known):
+    unknown, known = _c(unknown, np.float32), _c(known, np.float32)
+    B, n, _ = unknown.shape
+    m = known.shape[1]
+    d2 = np.empty((B, n, 3), np.float32)
+    idx = np.empty((B, n, 3), np.int32)
+    _chk(lib().tpgref_three_nn_f32(_f(unknown), _f(known), B, n, m, _f(d2), _i32(idx)), "three_nn")
+    return d2, idx
+
+
+def three_interp_fwd(feat, idx, w):
+    feat, idx, w = _c(feat, np.float32), _c(idx, np.int32), _c(w, np.float32)
+    B, Cc, m = feat.shape
+    n = idx.shape[1]
+    out = np.empty((B, Cc, n), np.float32)
+    _chk(lib().tpgref_three_interp_fwd_f32(_f(feat), _i32(idx), _f(w), B, Cc, m, n, _f(out)),
+         "three_interp_fwd")
+    return out
+
+
+def three_interp_bwd(gout, idx, w, m):
+    gout, idx, w = _c(gout, np.float32), _c(idx, np.int32), _c(w, np.float32)
+    B, Cc, n = gout.shape
+    g = np.empty((B, Cc, m), np.float32)
+    _chk(lib().tpgref_three_interp_bwd_f32(_f(gout), _i32(idx), _f(w), B, Cc, m, n, _f(g)),
+         "three_interp_bwd")
+    return g

@@ -1,0 +1,337 @@
+/*
+ * oracle/tpgref.c -- CPU restatement of the TPU-GAN neighbourhood ops.
+ *
+ * TEST INFRASTRUCTURE ONLY.  Nothing under oracle/ is part of the product path:
+ * only tests/, __graft_entry__.smoke() and bench.py's cpu_baseline leg may load
+ * this library, and only as the checker / reported CPU baseline.
+ *
+ * PARITY UNPINNED at op level: the arithmetic restated here lives upstream in
+ * four un-vendored, un-pinned third-party CUDA packages named only in
+ * /root/reference/README.md:5-8 (pointnet2_ops, pytorch3d, FRNN, chamferdist).
+ * None of them is present in the build container and the reference holds no
+ * tests, fixtures or golden vectors for them.  The
+ * semantics below are therefore the published algorithms restated from their
+ * documented behaviour and anchored on the reference's own call sites; the
+ * tie/ordering rules that upstream leaves undefined are fixed here ("canonical
+ * rules") and the HIP kernels are held bit-exact to THIS
+ * file.  Model-level parity (reference Python running over these ops) is
+ * pinned separately by tests/golden/.
+ *
+ * Canonical arithmetic (both here and in the csrc HIP sources, compiled -ffp-contract=off):
+ *   sqdist(a,b,D) = sum_d (a_d - b_d)^2, accumulated in d order, every
+ *   operation rounded to fp32, no FMA.
+ *   neighbour order = ascending lexicographic (dist, idx).
+ *
+ * Build: gcc -O2 -fopenmp -ffp-contract=off -fno-fast-math -shared -fPIC
+ */
+#include <math.h>
+#include <stdint.h>
+#include <stdlib.h>
+#include <string.h>
+
+#define TPG_OK 0
+#define TPG_ERR_ARG (-1)
+#define TPG_ERR_UNSUPPORTED (-3)
+
+static inline float sqdist(const float *a, const float *b, int D) {
+    float acc = 0.0f;
+    for (int d = 0; d < D; ++d) {
+        float t = a[d] - b[d];
+        float tt = t * t;
+        acc = acc + tt;
+    }
+    return acc;
+}
+
+/* ------------------------------------------------------------------------ */
+/* kNN / fixed-radius NN.                                                    */
+/* Replaces pytorch3d.ops.knn_points  (gcn_lib/pointnet/gcn.py:16-21,38;      */
+/*          discriminator.py:15,33) and frnn.frnn_grid_points                 */
+/*          (discriminator.py:27-32; loss.py:256-265).                        */
+/* r2 < 0  : plain kNN; slots beyond len2 get dist 0 / idx 0 (pytorch3d pad). */
+/* r2 >= 0 : keep only d < r2 (strict); unfilled slots dist -1 / idx -1.      */
+/* Rows of p1 beyond len1 are written as the pad value of the mode.           */
+/* ------------------------------------------------------------------------ */
+int tpgref_knn_f32(const float *p1, const float *p2, const int64_t *len1,
+                   const int64_t *len2, int B, int P1, int P2, int D, int K,
+                   float r2, float *dist, int64_t *idx) {
+    if (B < 0 || P1 < 0 || P2 < 0 || D <= 0 || K <= 0) return TPG_ERR_ARG;
+    const int radius = r2 >= 0.0f;
+    const float pad_d = radius ? -1.0f : 0.0f;
+    const int64_t pad_i = radius ? -1 : 0;
+#pragma omp parallel for collapse(2) schedule(static)
+    for (int b = 0; b < B; ++b) {
+        for (int i = 0; i < P1; ++i) {
+            float *od = dist + ((size_t)b * P1 + i) * K;
+            int64_t *oi = idx + ((size_t)b * P1 + i) * K;
+            for (int k = 0; k < K; ++k) { od[k] = pad_d; oi[k] = pad_i; }
+            const int n1 = len1 ? (int)len1[b] : P1;
+            const int n2 = len2 ? (int)len2[b] : P2;
+            if (i >= n1) continue;
+            const float *q = p1 + ((size_t)b * P1 + i) * D;
+            int cnt = 0; /* sorted prefix od[0..cnt) */
+            for (int j = 0; j < n2; ++j) {
+                const float d = sqdist(q, p2 + ((size_t)b * P2 + j) * D, D);
+                if (radius && !(d < r2)) continue;
+                if (cnt == K && !(d < od[K - 1])) continue; /* ties keep lower idx */
+                int pos = cnt < K ? cnt : K - 1;
+                while (pos > 0 && d < od[pos - 1]) { /* strict: equal stays behind */
+                    od[pos] = od[pos - 1]; oi[pos] = oi[pos - 1]; --pos;
+                }
+                od[pos] = d; oi[pos] = j;
+                if (cnt < K) ++cnt;
+            }
+        }
+    }
+    return TPG_OK;
+}
+
+/* ------------------------------------------------------------------------ */
+/* Chamfer nearest-neighbour search, both directions.                        */
+/* Replaces chamferdist.ChamferDistance (loss.py:125-127,176-181).           */
+/* d1[b,i] = min_j |s_i - t_j|^2, i1 = arg-min (lowest j on ties); d2/i2     */
+/* the same from t to s.                                                      */
+/* ------------------------------------------------------------------------ */
+int tpgref_chamfer_fwd_f32(const float *src, const float *tgt, int B, int N,
+                           int M, float *d1, int64_t *i1, float *d2, int64_t *i2) {
+    if (B < 0 || N <= 0 || M <= 0) return TPG_ERR_ARG;
+    int rc = tpgref_knn_f32(src, tgt, NULL, NULL, B, N, M, 3, 1, -1.0f, d1, i1);
+    if (rc) return rc;
+    return tpgref_knn_f32(tgt, src, NULL, NULL, B, M, N, 3, 1, -1.0f, d2, i2);
+}
+
+/* grad wrt both clouds given upstream grads of d1 (B,N) and d2 (B,M).       */
+/* Deterministic order: direct term first, then scatter terms in index order. */
+int tpgref_chamfer_bwd_f32(const float *src, const float *tgt, int B, int N, int M,
+                           const int64_t *i1, const int64_t *i2, const float *g1,
+                           const float *g2, float *gsrc, float *gtgt) {
+    if (B < 0 || N <= 0 || M <= 0) return TPG_ERR_ARG;
+    memset(gsrc, 0, sizeof(float) * (size_t)B * N * 3);
+    memset(gtgt, 0, sizeof(float) * (size_t)B * M * 3);
+#pragma omp parallel for schedule(static)
+    for (int b = 0; b < B; ++b) {
+        const float *s = src + (size_t)b * N * 3, *t = tgt + (size_t)b * M * 3;
+        float *gs = gsrc + (size_t)b * N * 3, *gt = gtgt + (size_t)b * M * 3;
+        for (int i = 0; i < N; ++i) {
+            const int64_t j = i1[(size_t)b * N + i];
+            const float g = 2.0f * g1[(size_t)b * N + i];
+            for (int c = 0; c < 3; ++c) {
+                const float v = g * (s[i * 3 + c] - t[j * 3 + c]);
+                gs[i * 3 + c] += v; gt[j * 3 + c] -= v;
+            }
+        }
+        for (int j = 0; j < M; ++j) {
+            const int64_t i = i2[(size_t)b * M + j];
+            const float g = 2.0f * g2[(size_t)b * M + j];
+            for (int c = 0; c < 3; ++c) {
+                const float v = g * (t[j * 3 + c] - s[i * 3 + c]);
+                gt[j * 3 + c] += v; gs[i * 3 + c] -= v;
+            }
+        }
+    }
+    return TPG_OK;
+}
+
+/* ------------------------------------------------------------------------ */
+/* Furthest point sampling.  Replaces pointnet2_utils.furthest_point_sample  */
+/* (discriminator.py:114).  idx[0]=0, temp=1e10, points with |x|^2 <= 1e-3    */
+/* are never updated nor eligible; arg-max ties -> smallest index (canonical */
+/* deviation from upstream's block-size dependent tree order).    */
+/* temp is caller-provided scratch (B,N).                                    */
+/* ------------------------------------------------------------------------ */
+int tpgref_fps_f32(const float *xyz, int B, int N, int m, float *temp, int32_t *idx) {
+    if (B < 0 || N <= 0 || m <= 0) return TPG_ERR_ARG;
+#pragma omp parallel for schedule(static)
+    for (int b = 0; b < B; ++b) {
+        const float *x = xyz + (size_t)b * N * 3;
+        float *tp = temp + (size_t)b * N;
+        int32_t *o = idx + (size_t)b * m;
+        for (int k = 0; k < N; ++k) tp[k] = 1e10f;
+        int old = 0;
+        o[0] = 0;
+        for (int j = 1; j < m; ++j) {
+            int besti = 0;
+            float best = -1.0f;
+            const float *xo = x + (size_t)old * 3;
+            for (int k = 0; k < N; ++k) {
+                const float *xk = x + (size_t)k * 3;
+                float mag = xk[0] * xk[0];
+                mag = mag + xk[1] * xk[1];
+                mag = mag + xk[2] * xk[2];
+                if (mag <= 1e-3f) continue;
+                const float d = sqdist(xk, xo, 3);
+                const float d2 = d < tp[k] ? d : tp[k];
+                tp[k] = d2;
+                if (d2 > best) { best = d2; besti = k; }
+            }
+            old = besti;
+            o[j] = old;
+        }
+    }
+    return TPG_OK;
+}
+
+/* ------------------------------------------------------------------------ */
+/* gather_operation fwd/bwd (discriminator.py:131-137).                      */
+/* ------------------------------------------------------------------------ */
+int tpgref_gather_fwd_f32(const float *feat, const int32_t *idx, int B, int C,
+                          int N, int S, float *out) {
+    if (B < 0 || C < 0 || N <= 0 || S < 0) return TPG_ERR_ARG;
+#pragma omp parallel for collapse(2) schedule(static)
+    for (int b = 0; b < B; ++b)
+        for (int c = 0; c < C; ++c)
+            for (int s = 0; s < S; ++s)
+                out[((size_t)b * C + c) * S + s] =
+                    feat[((size_t)b * C + c) * N + idx[(size_t)b * S + s]];
+    return TPG_OK;
+}
+
+int tpgref_gather_bwd_f32(const float *gout, const int32_t *idx, int B, int C,
+                          int N, int S, float *gfeat) {
+    if (B < 0 || C < 0 || N <= 0 || S < 0) return TPG_ERR_ARG;
+    memset(gfeat, 0, sizeof(float) * (size_t)B * C * N);
+#pragma omp parallel for collapse(2) schedule(static)
+    for (int b = 0; b < B; ++b)
+        for (int c = 0; c < C; ++c)
+            for (int s = 0; s < S; ++s)
+                gfeat[((size_t)b * C + c) * N + idx[(size_t)b * S + s]] +=
+                    gout[((size_t)b * C + c) * S + s];
+    return TPG_OK;
+}
+
+/* ------------------------------------------------------------------------ */
+/* ball_query (inside QueryAndGroup, discriminator.py:190).  Scan k in index */
+/* order, keep the first nsample with d < r^2; first hit pre-fills the row;   */
+/* no hit leaves the row at 0.                                                */
+/* ------------------------------------------------------------------------ */
+int tpgref_ball_query_f32(const float *xyz, const float *new_xyz, int B, int N,
+                          int S, float radius, int nsample, int32_t *idx) {
+    if (B < 0 || N <= 0 || S < 0 || nsample <= 0) return TPG_ERR_ARG;
+    const float r2 = radius * radius;
+#pragma omp parallel for collapse(2) schedule(static)
+    for (int b = 0; b < B; ++b) {
+        for (int s = 0; s < S; ++s) {
+            int32_t *o = idx + ((size_t)b * S + s) * nsample;
+            for (int l = 0; l < nsample; ++l) o[l] = 0;
+            const float *q = new_xyz + ((size_t)b * S + s) * 3;
+            int cnt = 0;
+            for (int k = 0; k < N && cnt < nsample; ++k) {
+                const float d = sqdist(q, xyz + ((size_t)b * N + k) * 3, 3);
+                if (d < r2) {
+                    if (cnt == 0)
+                        for (int l = 0; l < nsample; ++l) o[l] = k;
+                    o[cnt] = k;
+                    ++cnt;
+                }
+            }
+        }
+    }
+    return TPG_OK;
+}
+
+/* ------------------------------------------------------------------------ */
+/* grouping_operation fwd/bwd (gcn_lib/pointnet/gcn.py:207,261;              */
+/* discriminator.py:270,273).  bwd sums in (s,k) order.                       */
+/* ------------------------------------------------------------------------ */
+int tpgref_group_fwd_f32(const float *feat, const int32_t *idx, int B, int C,
+                         int N, int S, int K, float *out) {
+    if (B < 0 || C < 0 || N <= 0 || S < 0 || K < 0) return TPG_ERR_ARG;
+    const size_t SK = (size_t)S * K;
+#pragma omp parallel for collapse(2) schedule(static)
+    for (int b = 0; b < B; ++b)
+        for (int c = 0; c < C; ++c) {
+            const float *f = feat + ((size_t)b * C + c) * N;
+            const int32_t *id = idx + (size_t)b * SK;
+            float *o = out + ((size_t)b * C + c) * SK;
+            for (size_t e = 0; e < SK; ++e) o[e] = f[id[e]];
+        }
+    return TPG_OK;
+}
+
+int tpgref_group_bwd_f32(const float *gout, const int32_t *idx, int B, int C,
+                         int N, int S, int K, float *gfeat) {
+    if (B < 0 || C < 0 || N <= 0 || S < 0 || K < 0) return TPG_ERR_ARG;
+    const size_t SK = (size_t)S * K;
+    memset(gfeat, 0, sizeof(float) * (size_t)B * C * N);
+#pragma omp parallel for collapse(2) schedule(static)
+    for (int b = 0; b < B; ++b)
+        for (int c = 0; c < C; ++c) {
+            float *g = gfeat + ((size_t)b * C + c) * N;
+            const int32_t *id = idx + (size_t)b * SK;
+            const float *o = gout + ((size_t)b * C + c) * SK;
+            for (size_t e = 0; e < SK; ++e) g[id[e]] += o[e];
+        }
+    return TPG_OK;
+}
+
+/* ------------------------------------------------------------------------ */
+/* three_nn / three_interpolate (no call sites in the reference; exported     */
+/* for pointnet2_utils API completeness).  three_nn returns SQUARED distance  */
+/* here; the Python layer applies sqrt like upstream's wrapper.               */
+/* ------------------------------------------------------------------------ */
+int tpgref_three_nn_f32(const float *unknown, const float *known, int B, int n,
+                        int m, float *dist2, int32_t *idx) {
+    if (B < 0 || n < 0 || m <= 0) return TPG_ERR_ARG;
+#pragma omp parallel for collapse(2) schedule(static)
+    for (int b = 0; b < B; ++b)
+        for (int i = 0; i < n; ++i) {
+            const float *q = unknown + ((size_t)b * n + i) * 3;
+            float bd[3] = {INFINITY, INFINITY, INFINITY};
+            int32_t bi[3] = {0, 0, 0};
+            for (int k = 0; k < m; ++k) {
+                const float d = sqdist(q, known + ((size_t)b * m + k) * 3, 3);
+                if (d < bd[0]) {
+                    bd[2] = bd[1]; bi[2] = bi[1]; bd[1] = bd[0]; bi[1] = bi[0];
+                    bd[0] = d; bi[0] = k;
+                } else if (d < bd[1]) {
+                    bd[2] = bd[1]; bi[2] = bi[1]; bd[1] = d; bi[1] = k;
+                } else if (d < bd[2]) {
+                    bd[2] = d; bi[2] = k;
+                }
+            }
+            for (int l = 0; l < 3; ++l) {
+                dist2[((size_t)b * n + i) * 3 + l] = bd[l];
+                idx[((size_t)b * n + i) * 3 + l] = bi[l];
+            }
+        }
+    return TPG_OK;
+}
+
+int tpgref_three_interp_fwd_f32(const float *feat, const int32_t *idx,
+                                const float *w, int B, int C, int m, int n,
+                                float *out) {
+    if (B < 0 || C < 0 || m <= 0 || n < 0) return TPG_ERR_ARG;
+#pragma omp parallel for collapse(2) schedule(static)
+    for (int b = 0; b < B; ++b)
+        for (int c = 0; c < C; ++c) {
+            const float *f = feat + ((size_t)b * C + c) * m;
+            for (int i = 0; i < n; ++i) {
+                const int32_t *id = idx + ((size_t)b * n + i) * 3;
+                const float *ww = w + ((size_t)b * n + i) * 3;
+                float acc = ww[0] * f[id[0]];
+                acc = acc + ww[1] * f[id[1]];
+                acc = acc + ww[2] * f[id[2]];
+                out[((size_t)b * C + c) * n + i] = acc;
+            }
+        }
+    return TPG_OK;
+}
+
+int tpgref_three_interp_bwd_f32(const float *gout, const int32_t *idx,
+                                const float *w, int B, int C, int m, int n,
+                                float *gfeat) {
+    if (B < 0 || C < 0 || m <= 0 || n < 0) return TPG_ERR_ARG;
+    memset(gfeat, 0, sizeof(float) * (size_t)B * C * m);
+#pragma omp parallel for collapse(2) schedule(static)
+    for (int b = 0; b < B; ++b)
+        for (int c = 0; c < C; ++c) {
+            float *g = gfeat + ((size_t)b * C + c) * m;
+            for (int i = 0; i < n; ++i) {
+                const int32_t *id = idx + ((size_t)b * n + i) * 3;
+                const float *ww = w + ((size_t)b * n + i) * 3;
+                const float go = gout[((size_t)b * C + c) * n + i];
+                for (int l = 0; l < 3; ++l) g[id[l]] += go * ww[l];
+            }
+        }
+    return TPG_OK;
+}
