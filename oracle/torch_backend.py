@@ -1,0 +1,83 @@
+"""CPU-tensor op backend built on the C restatement.  TEST INFRASTRUCTURE ONLY.
+
+`install()` registers it with `tpgan_amd.ops` for CPU tensors so that (a) tests can
+run the host-side model code on CPU, (b) the golden-capture script can run the
+reference's Python over it in the build container, and (c) bench.py's
+`cpu_baseline` leg can time the same step function on the host cores.  The
+product never calls `install()`.
+"""
+import numpy as np
+import torch
+
+from . import ref_ops as R
+
+
+def _np(t):
+    return None if t is None else t.detach().cpu().numpy()
+
+
+def _t(a):
+    return torch.from_numpy(np.ascontiguousarray(a))
+
+
+class OracleBackend:
+    name = "oracle-cpu"
+
+    def knn(self, p1, p2, len1, len2, K, r2):
+        # ref_ops.knn squares r itself; pass sqrt-free by calling the C symbol directly
+        import ctypes as C
+        a, b = R._c(_np(p1), np.float32), R._c(_np(p2), np.float32)
+        B, P1, D = a.shape
+        P2 = b.shape[1]
+        l1 = None if len1 is None else R._c(_np(len1), np.int64)
+        l2 = None if len2 is None else R._c(_np(len2), np.int64)
+        dist = np.empty((B, P1, K), np.float32)
+        idx = np.empty((B, P1, K), np.int64)
+        R._chk(R.lib().tpgref_knn_f32(R._f(a), R._f(b), R._i64(l1), R._i64(l2), B, P1, P2, D, K,
+                                      C.c_float(-1.0 if r2 is None else r2), R._f(dist), R._i64(idx)),
+               "knn")
+        return _t(dist), _t(idx)
+
+    def chamfer_fwd(self, src, tgt):
+        return tuple(_t(x) for x in R.chamfer_fwd(_np(src), _np(tgt)))
+
+    def chamfer_bwd(self, src, tgt, i1, i2, g1, g2):
+        return tuple(_t(x) for x in R.chamfer_bwd(_np(src), _np(tgt), _np(i1), _np(i2), _np(g1), _np(g2)))
+
+    def fps(self, xyz, m):
+        return _t(R.fps(_np(xyz), m))
+
+    def gather_fwd(self, feat, idx):
+        return _t(R.gather_fwd(_np(feat), _np(idx)))
+
+    def gather_bwd(self, gout, idx, N):
+        return _t(R.gather_bwd(_np(gout), _np(idx), N))
+
+    def ball_query(self, radius, nsample, xyz, new_xyz):
+        return _t(R.ball_query(radius, nsample, _np(xyz), _np(new_xyz)))
+
+    def group_fwd(self, feat, idx):
+        return _t(R.group_fwd(_np(feat), _np(idx)))
+
+    def group_bwd(self, gout, idx, N):
+        return _t(R.group_bwd(_np(gout), _np(idx), N))
+
+    def three_nn(self, unknown, known):
+        d2, idx = R.three_nn(_np(unknown), _np(known))
+        return _t(d2), _t(idx)
+
+    def three_interp_fwd(self, feat, idx, w):
+        return _t(R.three_interp_fwd(_np(feat), _np(idx), _np(w)))
+
+    def three_interp_bwd(self, gout, idx, w, m):
+        return _t(R.three_interp_bwd(_np(gout), _np(idx), _np(w), m))
+
+
+def install():
+    import tpgan_amd.ops as ops
+    ops.register_backend("cpu", OracleBackend())
+
+
+def uninstall():
+    import tpgan_amd.ops as ops
+    ops.unregister_backend("cpu")

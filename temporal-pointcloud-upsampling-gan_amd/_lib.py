@@ -1,0 +1,66 @@
+"""ctypes binding of libtpgan_hip.so (the C-ABI declared in include/tpgan_ops.h).
+
+This is the binding a maintainer of the reference would add in place of the
+`pointnet2_ops._ext`, `pytorch3d._C`, `frnn._C` and `chamferdist` extension
+modules.  There is NO fallback: if the library is missing the
+product path raises, it never routes through a CPU implementation.
+"""
+import ctypes as C
+import os
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "csrc", "libtpgan_hip.so")
+
+_P = C.c_void_p
+_I = C.c_int
+_F = C.c_float
+
+# symbol -> argtypes (restype is always int except the two string getters)
+SIGNATURES = {
+    "tpg_knn_f32": [_P, _P, _P, _P, _I, _I, _I, _I, _I, _F, _P, _P, _P],
+    "tpg_chamfer_fwd_f32": [_P, _P, _I, _I, _I, _P, _P, _P, _P, _P],
+    "tpg_chamfer_bwd_f32": [_P, _P, _I, _I, _I, _P, _P, _P, _P, _P, _P, _P],
+    "tpg_fps_f32": [_P, _I, _I, _I, _P, _P, _P],
+    "tpg_gather_fwd_f32": [_P, _P, _I, _I, _I, _I, _P, _P],
+    "tpg_gather_bwd_f32": [_P, _P, _I, _I, _I, _I, _P, _P],
+    "tpg_ball_query_f32": [_P, _P, _I, _I, _I, _F, _I, _P, _P],
+    "tpg_group_fwd_f32": [_P, _P, _I, _I, _I, _I, _I, _P, _P],
+    "tpg_group_bwd_f32": [_P, _P, _I, _I, _I, _I, _I, _P, _P],
+    "tpg_three_nn_f32": [_P, _P, _I, _I, _I, _P, _P, _P],
+    "tpg_three_interp_fwd_f32": [_P, _P, _P, _I, _I, _I, _I, _P, _P],
+    "tpg_three_interp_bwd_f32": [_P, _P, _P, _I, _I, _I, _I, _P, _P],
+}
+STRING_GETTERS = ("tpg_version", "tpg_target_arch")
+
+STATUS = {0: "TPG_OK", -1: "TPG_ERR_ARG", -2: "TPG_ERR_LAUNCH", -3: "TPG_ERR_UNSUPPORTED"}
+
+_lib = None
+
+
+class HipLibraryMissing(RuntimeError):
+    pass
+
+
+def load():
+    """dlopen the HIP library (once).  Raises HipLibraryMissing loudly if absent."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise HipLibraryMissing(
+            f"{LIB_PATH} not found: build it with `python __graft_entry__.py` "
+            "(hipcc --offload-arch=gfx950).  There is no CPU fallback.")
+    lib = C.CDLL(LIB_PATH)
+    for name, argtypes in SIGNATURES.items():
+        fn = getattr(lib, name)
+        fn.argtypes = argtypes
+        fn.restype = C.c_int
+    for name in STRING_GETTERS:
+        getattr(lib, name).restype = C.c_char_p
+    _lib = lib
+    return lib
+
+
+def check(rc, name):
+    if rc != 0:
+        raise RuntimeError(f"{name} failed: {STATUS.get(rc, rc)}")

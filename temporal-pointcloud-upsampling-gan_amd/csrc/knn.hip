@@ -1,0 +1,240 @@
+// K nearest neighbours / fixed-radius neighbours / Chamfer nn-search for gfx950.
+//
+// Replaces pytorch3d.ops.knn_points (reference gcn_lib/pointnet/gcn.py:16-21,38,258;
+// discriminator.py:15-20,33-38), frnn.frnn_grid_points (discriminator.py:27-32;
+// loss.py:256-265) and the nn-search of chamferdist.ChamferDistance
+// (loss.py:125-127,176-181).
+//
+// Design (one wave64 per query, no LDS for the neighbour list):
+//   * the 64 lanes of a wave test 64 consecutive candidates per step; each lane
+//     reads its own candidate row (D contiguous floats, 16-B vector loads) while
+//     the query row is broadcast from LDS;
+//   * a candidate is the 64-bit key (dist_bits << 32 | idx): keys are unique
+//     and their unsigned order IS the canonical (dist, idx) order;
+//   * the running K best keys live one per lane, sorted ascending across the
+//     wave (K <= 64).  A candidate that beats the K-th key is inserted with a
+//     ballot (rank = popcount of lanes holding a smaller key) and a one-lane
+//     shift -- no shared memory, no sorting network, no per-thread heap;
+//   * after warm-up almost every 64-candidate step fails the threshold test
+//     with one v_cmp + ballot, so the loop runs at the distance-evaluation rate;
+//   * K == 1 (Chamfer, masking loss) never leaves the lane: per-lane running
+//     minimum, one DPP wave reduction at the end.
+// The kernel is HBM/L2-light (each cloud is a few KB..1.5 MB and stays in L2);
+// its bound is VALU issue + cross-lane latency, see DESIGN.md.
+#include "tpg_common.hpp"
+
+namespace {
+
+constexpr int KNN_WAVES = 4;  // waves (= queries) per workgroup
+
+__device__ __forceinline__ tpg_u64 knn_pack(float d, int j) {
+    return ((tpg_u64)__float_as_uint(d) << 32) | (unsigned)j;
+}
+
+// distance between the wave's query (LDS, broadcast reads) and this lane's row.
+template <int D_T>
+__device__ __forceinline__ float knn_dist(const float *__restrict__ qs,
+                                          const float *__restrict__ c, int D) {
+    float acc = 0.0f;
+    if constexpr (D_T == 3) {
+        const float t0 = qs[0] - c[0], t1 = qs[1] - c[1], t2 = qs[2] - c[2];
+        acc = t0 * t0;
+        acc = acc + t1 * t1;
+        acc = acc + t2 * t2;
+    } else if constexpr (D_T > 0) {
+        static_assert(D_T % 4 == 0, "vector path needs D % 4 == 0");
+        const float4 *c4 = reinterpret_cast<const float4 *>(c);
+        const float4 *q4 = reinterpret_cast<const float4 *>(qs);
+#pragma unroll
+        for (int d = 0; d < D_T / 4; ++d) {
+            const float4 cv = c4[d];
+            const float4 qv = q4[d];
+            float t;
+            t = qv.x - cv.x; acc = acc + t * t;
+            t = qv.y - cv.y; acc = acc + t * t;
+            t = qv.z - cv.z; acc = acc + t * t;
+            t = qv.w - cv.w; acc = acc + t * t;
+        }
+    } else {
+        for (int d = 0; d < D; ++d) {
+            const float t = qs[d] - c[d];
+            acc = acc + t * t;
+        }
+    }
+    return acc;
+}
+
+template <int D_T, bool RADIUS>
+__global__ __launch_bounds__(KNN_WAVES * 64) void knn_kernel(
+    const float *__restrict__ p1, const float *__restrict__ p2,
+    const int64_t *__restrict__ len1, const int64_t *__restrict__ len2, int B, int P1, int P2,
+    int D, int K, float r2, float *__restrict__ dist, int64_t *__restrict__ idx) {
+    extern __shared__ __attribute__((aligned(16))) float knn_q[];  // [KNN_WAVES][Dpad]
+    const int lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int Dpad = (D + 3) & ~3;
+    float *qs = knn_q + wave * Dpad;
+
+    const int b = blockIdx.y;
+    const int i = blockIdx.x * KNN_WAVES + wave;
+    const bool valid = i < P1;
+    const size_t q = (size_t)b * P1 + (valid ? i : 0);
+    const int n1 = len1 ? (int)len1[b] : P1;
+    const int n2 = len2 ? min((int)len2[b], P2) : P2;
+
+    // stage the query row (each wave its own slice; the barrier orders LDS)
+    if (valid) {
+        const float *qrow = p1 + q * D;
+        for (int d = lane; d < D; d += 64) qs[d] = qrow[d];
+    }
+    __syncthreads();
+    if (!valid) return;
+
+    const float pad_d = RADIUS ? -1.0f : 0.0f;
+    const long long pad_i = RADIUS ? -1 : 0;
+    float *od = dist + q * K;
+    int64_t *oi = idx + q * K;
+    if (i >= n1 || n2 <= 0) {
+        for (int k = lane; k < K; k += 64) { od[k] = pad_d; oi[k] = pad_i; }
+        return;
+    }
+
+    const float *cbase = p2 + (size_t)b * P2 * D;
+    const tpg_u64 INF = ~0ull;
+
+    if (K == 1) {
+        tpg_u64 best = INF;
+        for (int j = lane; j < n2; j += 64) {
+            const float d = knn_dist<D_T>(qs, cbase + (size_t)j * D, D);
+            if (!RADIUS || d < r2) {
+                const tpg_u64 key = knn_pack(d, j);
+                best = key < best ? key : best;
+            }
+        }
+        best = tpg_wave_min_u64(best);
+        if (lane == 0) {
+            if (best == INF) { od[0] = pad_d; oi[0] = pad_i; }
+            else { od[0] = __uint_as_float((unsigned)(best >> 32)); oi[0] = (long long)(unsigned)best; }
+        }
+        return;
+    }
+
+    tpg_u64 best = INF;  // lane l: l-th smallest key so far
+    tpg_u64 thr = INF;   // wave-uniform: key of rank K-1
+    for (int base = 0; base < n2; base += 64) {
+        const int j = base + lane;
+        tpg_u64 key = INF;
+        if (j < n2) {
+            const float d = knn_dist<D_T>(qs, cbase + (size_t)j * D, D);
+            if (!RADIUS || d < r2) key = knn_pack(d, j);
+        }
+        tpg_u64 mask = __ballot(key < thr);
+        while (mask) {
+            const int src = __builtin_amdgcn_readfirstlane(__builtin_ctzll(mask));
+            mask &= mask - 1;
+            const tpg_u64 x = tpg_readlane_u64(key, src);
+            if (x < thr) {  // wave-uniform: thr may have dropped since the ballot
+                const int pos = __popcll(__ballot(best < x));
+                const tpg_u64 up = __shfl_up(best, 1);
+                best = lane < pos ? best : (lane == pos ? x : up);
+                thr = tpg_readlane_u64(best, K - 1);
+            }
+        }
+    }
+    if (lane < K) {
+        if (best == INF) { od[lane] = pad_d; oi[lane] = pad_i; }
+        else {
+            od[lane] = __uint_as_float((unsigned)(best >> 32));
+            oi[lane] = (long long)(unsigned)best;
+        }
+    }
+}
+
+template <bool RADIUS>
+int knn_launch(const float *p1, const float *p2, const int64_t *len1, const int64_t *len2, int B,
+               int P1, int P2, int D, int K, float r2, float *dist, int64_t *idx,
+               hipStream_t st) {
+    if (B == 0 || P1 == 0) return TPG_OK;
+    if (B > 65535) return TPG_ERR_ARG;
+    const dim3 grid((unsigned)((P1 + KNN_WAVES - 1) / KNN_WAVES), (unsigned)B), block(KNN_WAVES * 64);
+    const size_t smem = sizeof(float) * KNN_WAVES * ((D + 3) & ~3);
+    if (smem > 64 * 1024) return TPG_ERR_UNSUPPORTED;
+    // the vector path also needs 16-B aligned rows: D % 4 == 0 and aligned bases
+    const bool al = ((reinterpret_cast<uintptr_t>(p1) | reinterpret_cast<uintptr_t>(p2)) & 15) == 0;
+#define TPG_KNN_GO(DT) \
+    hipLaunchKernelGGL((knn_kernel<DT, RADIUS>), grid, block, smem, st, p1, p2, len1, len2, B, P1, \
+                       P2, D, K, r2, dist, idx)
+    if (D == 3) TPG_KNN_GO(3);
+    else if (D == 32 && al) TPG_KNN_GO(32);
+    else if (D == 64 && al) TPG_KNN_GO(64);
+    else TPG_KNN_GO(0);
+#undef TPG_KNN_GO
+    TPG_RETURN_IF_LAUNCH_FAILED();
+    return TPG_OK;
+}
+
+// grads of both Chamfer directions; all contributions land by atomics (tolerance
+// 1e-5 against the ordered CPU sum).
+__global__ __launch_bounds__(256) void chamfer_bwd_kernel(
+    const float *__restrict__ a, const float *__restrict__ bcloud, int B, int N, int M,
+    const int64_t *__restrict__ nn, const float *__restrict__ g, float *__restrict__ ga,
+    float *__restrict__ gb) {
+    const long long t = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= (long long)B * N) return;
+    const int b = (int)(t / N);
+    long long j = nn[t];
+    j = j < 0 ? 0 : (j >= M ? M - 1 : j);
+    const float gg = 2.0f * g[t];
+    const float *pa = a + (size_t)t * 3;
+    const float *pb = bcloud + ((size_t)b * M + j) * 3;
+    float *oa = ga + (size_t)t * 3;
+    float *ob = gb + ((size_t)b * M + j) * 3;
+#pragma unroll
+    for (int c = 0; c < 3; ++c) {
+        const float v = gg * (pa[c] - pb[c]);
+        atomicAdd(oa + c, v);
+        atomicAdd(ob + c, -v);
+    }
+}
+
+}  // namespace
+
+extern "C" int tpg_knn_f32(const float *p1, const float *p2, const int64_t *len1,
+                           const int64_t *len2, int B, int P1, int P2, int D, int K, float r2,
+                           float *dist, int64_t *idx, void *stream) {
+    if (B < 0 || P1 < 0 || P2 < 0 || D <= 0 || K <= 0) return TPG_ERR_ARG;
+    if (K > TPG_MAX_K) return TPG_ERR_UNSUPPORTED;
+    if ((long long)B * P1 == 0) return TPG_OK;
+    if (!p1 || !dist || !idx || (P2 > 0 && !p2)) return TPG_ERR_ARG;
+    if (r2 >= 0.0f)
+        return knn_launch<true>(p1, p2, len1, len2, B, P1, P2, D, K, r2, dist, idx, tpg_stream(stream));
+    return knn_launch<false>(p1, p2, len1, len2, B, P1, P2, D, K, r2, dist, idx, tpg_stream(stream));
+}
+
+extern "C" int tpg_chamfer_fwd_f32(const float *src, const float *tgt, int B, int N, int M,
+                                   float *d1, int64_t *i1, float *d2, int64_t *i2, void *stream) {
+    if (B < 0 || N <= 0 || M <= 0) return TPG_ERR_ARG;
+    if (B == 0) return TPG_OK;
+    if (!src || !tgt || !d1 || !i1 || !d2 || !i2) return TPG_ERR_ARG;
+    int rc = knn_launch<false>(src, tgt, nullptr, nullptr, B, N, M, 3, 1, -1.0f, d1, i1, tpg_stream(stream));
+    if (rc) return rc;
+    return knn_launch<false>(tgt, src, nullptr, nullptr, B, M, N, 3, 1, -1.0f, d2, i2, tpg_stream(stream));
+}
+
+extern "C" int tpg_chamfer_bwd_f32(const float *src, const float *tgt, int B, int N, int M,
+                                   const int64_t *i1, const int64_t *i2, const float *g1,
+                                   const float *g2, float *gsrc, float *gtgt, void *stream) {
+    if (B < 0 || N <= 0 || M <= 0) return TPG_ERR_ARG;
+    if (B == 0) return TPG_OK;
+    if (!src || !tgt || !i1 || !i2 || !g1 || !g2 || !gsrc || !gtgt) return TPG_ERR_ARG;
+    hipStream_t st = tpg_stream(stream);
+    if (hipMemsetAsync(gsrc, 0, sizeof(float) * (size_t)B * N * 3, st) != hipSuccess) return TPG_ERR_LAUNCH;
+    if (hipMemsetAsync(gtgt, 0, sizeof(float) * (size_t)B * M * 3, st) != hipSuccess) return TPG_ERR_LAUNCH;
+    const long long t1 = (long long)B * N, t2 = (long long)B * M;
+    hipLaunchKernelGGL(chamfer_bwd_kernel, dim3((unsigned)((t1 + 255) / 256)), dim3(256), 0, st, src,
+                       tgt, B, N, M, i1, g1, gsrc, gtgt);
+    hipLaunchKernelGGL(chamfer_bwd_kernel, dim3((unsigned)((t2 + 255) / 256)), dim3(256), 0, st, tgt,
+                       src, B, M, N, i2, g2, gtgt, gsrc);
+    TPG_RETURN_IF_LAUNCH_FAILED();
+    return TPG_OK;
+}

@@ -1,0 +1,73 @@
+// Shared device helpers for the gfx950 kernels.  wave = 64 lanes everywhere.
+//
+// Every translation unit is compiled with -ffp-contract=off: the canonical
+// distance sum_d (a_d-b_d)^2 must round each mul and add separately so that
+// neighbour indices are bit-exact against oracle/tpgref.c.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "tpgan_ops.h"
+
+#define TPG_WAVE 64
+
+#define TPG_RETURN_IF_LAUNCH_FAILED()                         \
+    do {                                                      \
+        if (hipGetLastError() != hipSuccess) return TPG_ERR_LAUNCH; \
+    } while (0)
+
+typedef unsigned long long tpg_u64;
+
+static inline hipStream_t tpg_stream(void *s) { return reinterpret_cast<hipStream_t>(s); }
+
+__device__ __forceinline__ float tpg_sq3(float ax, float ay, float az, float bx, float by,
+                                         float bz) {
+    const float dx = ax - bx, dy = ay - by, dz = az - bz;
+    float s = dx * dx;
+    s = s + dy * dy;
+    s = s + dz * dz;
+    return s;
+}
+
+// ---- DPP cross-lane moves (gfx9 encodings) --------------------------------
+// quad_perm [1,0,3,2] = 0xB1, [2,3,0,1] = 0x4E, row_ror:n = 0x120+n,
+// row_bcast:15 = 0x142, row_bcast:31 = 0x143, wave_shr:1 = 0x138.
+template <int CTRL, int ROW_MASK = 0xF>
+__device__ __forceinline__ unsigned tpg_dpp_u32(unsigned v) {
+    return (unsigned)__builtin_amdgcn_update_dpp((int)v, (int)v, CTRL, ROW_MASK, 0xF, false);
+}
+template <int CTRL, int ROW_MASK = 0xF>
+__device__ __forceinline__ tpg_u64 tpg_dpp_u64(tpg_u64 v) {
+    const unsigned lo = tpg_dpp_u32<CTRL, ROW_MASK>((unsigned)v);
+    const unsigned hi = tpg_dpp_u32<CTRL, ROW_MASK>((unsigned)(v >> 32));
+    return ((tpg_u64)hi << 32) | lo;
+}
+
+__device__ __forceinline__ tpg_u64 tpg_readlane_u64(tpg_u64 v, int lane_uniform) {
+    const unsigned lo = (unsigned)__builtin_amdgcn_readlane((int)(unsigned)v, lane_uniform);
+    const unsigned hi = (unsigned)__builtin_amdgcn_readlane((int)(unsigned)(v >> 32), lane_uniform);
+    return ((tpg_u64)hi << 32) | lo;
+}
+
+// max over the wave, result broadcast to every lane (wave-uniform value).
+__device__ __forceinline__ tpg_u64 tpg_wave_max_u64(tpg_u64 v) {
+    tpg_u64 o;
+    o = tpg_dpp_u64<0xB1>(v); v = o > v ? o : v;          // xor 1
+    o = tpg_dpp_u64<0x4E>(v); v = o > v ? o : v;          // xor 2
+    o = tpg_dpp_u64<0x124>(v); v = o > v ? o : v;         // row_ror 4
+    o = tpg_dpp_u64<0x128>(v); v = o > v ? o : v;         // row_ror 8 -> row totals
+    o = tpg_dpp_u64<0x142, 0xA>(v); v = o > v ? o : v;    // row_bcast 15 into rows 1,3
+    o = tpg_dpp_u64<0x143, 0xC>(v); v = o > v ? o : v;    // row_bcast 31 into rows 2,3
+    return tpg_readlane_u64(v, 63);
+}
+
+__device__ __forceinline__ tpg_u64 tpg_wave_min_u64(tpg_u64 v) {
+    return ~tpg_wave_max_u64(~v);
+}
+
+// clamp an index into [0, n) -- invalid indices are undefined behaviour upstream;
+// here they must never fault the GPU.
+__device__ __forceinline__ int tpg_clamp_idx(int id, int n) {
+    const unsigned u = (unsigned)id;
+    return (int)(u < (unsigned)n ? u : (unsigned)(n - 1));
+}

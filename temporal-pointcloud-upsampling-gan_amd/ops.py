@@ -1,0 +1,408 @@
+"""Host-side operator layer: torch tensors in, C-ABI calls out, autograd glue.
+
+The functional API here is what the import-compatible modules in ``compat/``
+(pointnet2_ops, pytorch3d.ops, frnn, chamferdist) and the model code call.
+
+Device dispatch: CUDA/HIP tensors go to libtpgan_hip.so.  CPU tensors raise --
+like upstream's "CPU not supported" -- unless a test or the bench's cpu_baseline
+leg has explicitly registered a checker backend with ``register_backend('cpu',
+...)``; the product never registers one itself and never imports ``oracle``.
+"""
+import ctypes as C
+
+import numpy as np
+import torch
+
+from . import _lib
+
+_BACKENDS = {}
+
+
+def register_backend(device_type, impl):
+    """Install an op backend for a non-HIP device type (tests / cpu_baseline only)."""
+    if device_type == "cuda":
+        raise ValueError("the cuda backend is the HIP library and cannot be replaced")
+    _BACKENDS[device_type] = impl
+
+
+def unregister_backend(device_type):
+    _BACKENDS.pop(device_type, None)
+
+
+def radius_sq(r):
+    """python float radius -> fp32 r*r, the value both backends compare against."""
+    r32 = np.float32(r)
+    return float(np.float32(r32 * r32))
+
+
+def _ptr(t):
+    return None if t is None else C.c_void_p(t.data_ptr())
+
+
+def _stream(t):
+    return C.c_void_p(torch.cuda.current_stream(t.device).cuda_stream)
+
+
+class _DeviceGuard:
+    """Make `t.device` current for the duration of a launch (no-op when it already is)."""
+
+    def __init__(self, t):
+        self.idx = t.device.index
+        self.prev = None
+
+    def __enter__(self):
+        cur = torch.cuda.current_device()
+        if self.idx is not None and cur != self.idx:
+            self.prev = cur
+            torch.cuda.set_device(self.idx)
+
+    def __exit__(self, *a):
+        if self.prev is not None:
+            torch.cuda.set_device(self.prev)
+
+
+class HipBackend:
+    """Raw (non-autograd) ops on HIP tensors through the C-ABI."""
+
+    name = "hip"
+
+    def __init__(self):
+        self.lib = _lib.load()
+
+    def knn(self, p1, p2, len1, len2, K, r2):
+        B, P1, D = p1.shape
+        P2 = p2.shape[1]
+        dist = torch.empty((B, P1, K), dtype=torch.float32, device=p1.device)
+        idx = torch.empty((B, P1, K), dtype=torch.int64, device=p1.device)
+        with _DeviceGuard(p1):
+            _lib.check(self.lib.tpg_knn_f32(_ptr(p1), _ptr(p2), _ptr(len1), _ptr(len2), B, P1, P2, D, K,
+                                            -1.0 if r2 is None else r2, _ptr(dist), _ptr(idx),
+                                            _stream(p1)), "tpg_knn_f32")
+        return dist, idx
+
+    def chamfer_fwd(self, src, tgt):
+        B, N, _ = src.shape
+        M = tgt.shape[1]
+        d1 = torch.empty((B, N), dtype=torch.float32, device=src.device)
+        i1 = torch.empty((B, N), dtype=torch.int64, device=src.device)
+        d2 = torch.empty((B, M), dtype=torch.float32, device=src.device)
+        i2 = torch.empty((B, M), dtype=torch.int64, device=src.device)
+        with _DeviceGuard(src):
+            _lib.check(self.lib.tpg_chamfer_fwd_f32(_ptr(src), _ptr(tgt), B, N, M, _ptr(d1), _ptr(i1),
+                                                    _ptr(d2), _ptr(i2), _stream(src)),
+                       "tpg_chamfer_fwd_f32")
+        return d1, i1, d2, i2
+
+    def chamfer_bwd(self, src, tgt, i1, i2, g1, g2):
+        B, N, _ = src.shape
+        M = tgt.shape[1]
+        gs, gt = torch.empty_like(src), torch.empty_like(tgt)
+        with _DeviceGuard(src):
+            _lib.check(self.lib.tpg_chamfer_bwd_f32(_ptr(src), _ptr(tgt), B, N, M, _ptr(i1), _ptr(i2),
+                                                    _ptr(g1), _ptr(g2), _ptr(gs), _ptr(gt),
+                                                    _stream(src)), "tpg_chamfer_bwd_f32")
+        return gs, gt
+
+    def fps(self, xyz, m):
+        B, N, _ = xyz.shape
+        idx = torch.empty((B, m), dtype=torch.int32, device=xyz.device)
+        temp = torch.empty((B, N), dtype=torch.float32, device=xyz.device) if N > 16384 else None
+        with _DeviceGuard(xyz):
+            _lib.check(self.lib.tpg_fps_f32(_ptr(xyz), B, N, m, _ptr(temp), _ptr(idx), _stream(xyz)),
+                       "tpg_fps_f32")
+        return idx
+
+    def gather_fwd(self, feat, idx):
+        B, Cc, N = feat.shape
+        S = idx.shape[1]
+        out = torch.empty((B, Cc, S), dtype=torch.float32, device=feat.device)
+        with _DeviceGuard(feat):
+            _lib.check(self.lib.tpg_gather_fwd_f32(_ptr(feat), _ptr(idx), B, Cc, N, S, _ptr(out),
+                                                   _stream(feat)), "tpg_gather_fwd_f32")
+        return out
+
+    def gather_bwd(self, gout, idx, N):
+        B, Cc, S = gout.shape
+        g = torch.empty((B, Cc, N), dtype=torch.float32, device=gout.device)
+        with _DeviceGuard(gout):
+            _lib.check(self.lib.tpg_gather_bwd_f32(_ptr(gout), _ptr(idx), B, Cc, N, S, _ptr(g),
+                                                   _stream(gout)), "tpg_gather_bwd_f32")
+        return g
+
+    def ball_query(self, radius, nsample, xyz, new_xyz):
+        B, N, _ = xyz.shape
+        S = new_xyz.shape[1]
+        idx = torch.empty((B, S, nsample), dtype=torch.int32, device=xyz.device)
+        with _DeviceGuard(xyz):
+            _lib.check(self.lib.tpg_ball_query_f32(_ptr(xyz), _ptr(new_xyz), B, N, S, float(radius),
+                                                   nsample, _ptr(idx), _stream(xyz)),
+                       "tpg_ball_query_f32")
+        return idx
+
+    def group_fwd(self, feat, idx):
+        B, Cc, N = feat.shape
+        _, S, K = idx.shape
+        out = torch.empty((B, Cc, S, K), dtype=torch.float32, device=feat.device)
+        with _DeviceGuard(feat):
+            _lib.check(self.lib.tpg_group_fwd_f32(_ptr(feat), _ptr(idx), B, Cc, N, S, K, _ptr(out),
+                                                  _stream(feat)), "tpg_group_fwd_f32")
+        return out
+
+    def group_bwd(self, gout, idx, N):
+        B, Cc, S, K = gout.shape
+        g = torch.empty((B, Cc, N), dtype=torch.float32, device=gout.device)
+        with _DeviceGuard(gout):
+            _lib.check(self.lib.tpg_group_bwd_f32(_ptr(gout), _ptr(idx), B, Cc, N, S, K, _ptr(g),
+                                                  _stream(gout)), "tpg_group_bwd_f32")
+        return g
+
+    def three_nn(self, unknown, known):
+        B, n, _ = unknown.shape
+        m = known.shape[1]
+        d2 = torch.empty((B, n, 3), dtype=torch.float32, device=unknown.device)
+        idx = torch.empty((B, n, 3), dtype=torch.int32, device=unknown.device)
+        with _DeviceGuard(unknown):
+            _lib.check(self.lib.tpg_three_nn_f32(_ptr(unknown), _ptr(known), B, n, m, _ptr(d2), _ptr(idx),
+                                                 _stream(unknown)), "tpg_three_nn_f32")
+        return d2, idx
+
+    def three_interp_fwd(self, feat, idx, w):
+        B, Cc, m = feat.shape
+        n = idx.shape[1]
+        out = torch.empty((B, Cc, n), dtype=torch.float32, device=feat.device)
+        with _DeviceGuard(feat):
+            _lib.check(self.lib.tpg_three_interp_fwd_f32(_ptr(feat), _ptr(idx), _ptr(w), B, Cc, m, n,
+                                                         _ptr(out), _stream(feat)),
+                       "tpg_three_interp_fwd_f32")
+        return out
+
+    def three_interp_bwd(self, gout, idx, w, m):
+        B, Cc, n = gout.shape
+        g = torch.empty((B, Cc, m), dtype=torch.float32, device=gout.device)
+        with _DeviceGuard(gout):
+            _lib.check(self.lib.tpg_three_interp_bwd_f32(_ptr(gout), _ptr(idx), _ptr(w), B, Cc, m, n,
+                                                         _ptr(g), _stream(gout)),
+                       "tpg_three_interp_bwd_f32")
+        return g
+
+
+_hip = None
+
+
+def backend_for(t):
+    global _hip
+    if t.is_cuda:
+        if _hip is None:
+            _hip = HipBackend()  # raises HipLibraryMissing loudly if the .so is absent
+        return _hip
+    impl = _BACKENDS.get(t.device.type)
+    if impl is None:
+        raise RuntimeError(
+            f"tpgan_amd ops: {t.device.type} tensors are not supported (HIP only); "
+            "the product has no CPU fallback")
+    return impl
+
+
+# ----------------------------------------------------------------- validation
+def _need(cond, msg):
+    if not cond:
+        raise RuntimeError(msg)
+
+
+def _check_float(t, name, ndim):
+    _need(isinstance(t, torch.Tensor), f"{name} must be a tensor")
+    _need(t.dim() == ndim, f"{name} must have {ndim} dims, got {tuple(t.shape)}")
+    _need(t.dtype == torch.float32, f"{name} must be a float tensor, got {t.dtype}")
+    _need(t.is_contiguous(), f"{name} must be a contiguous tensor")
+
+
+def _check_int(t, name, ndim):
+    _need(isinstance(t, torch.Tensor), f"{name} must be a tensor")
+    _need(t.dim() == ndim, f"{name} must have {ndim} dims, got {tuple(t.shape)}")
+    _need(t.dtype == torch.int32, f"{name} must be an int tensor, got {t.dtype}")
+    _need(t.is_contiguous(), f"{name} must be a contiguous tensor")
+
+
+def _same_device(*ts):
+    d = ts[0].device
+    for t in ts[1:]:
+        _need(t.device == d, "all tensors must be on the same device")
+
+
+# --------------------------------------------------------- pointnet2-style ops
+def furthest_point_sample(xyz, npoint):
+    """(B,N,3) fp32 -> (B,npoint) int32.  Reference call site discriminator.py:114."""
+    _check_float(xyz, "xyz", 3)
+    _need(xyz.shape[2] == 3, "xyz must be (B,N,3)")
+    _need(int(npoint) > 0 and xyz.shape[1] > 0, "npoint and N must be positive")
+    with torch.no_grad():
+        return backend_for(xyz).fps(xyz.detach(), int(npoint))
+
+
+class _Gather(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, features, idx):
+        _check_float(features, "features", 3)
+        _check_int(idx, "idx", 2)
+        _same_device(features, idx)
+        ctx.save_for_backward(idx)
+        ctx.N = features.shape[2]
+        return backend_for(features).gather_fwd(features, idx)
+
+    @staticmethod
+    def backward(ctx, grad_out):
+        (idx,) = ctx.saved_tensors
+        g = backend_for(grad_out).gather_bwd(grad_out.contiguous().float(), idx, ctx.N)
+        return g, None
+
+
+def gather_operation(features, idx):
+    """(B,C,N),(B,S) int32 -> (B,C,S).  Reference call site discriminator.py:131-137."""
+    return _Gather.apply(features, idx)
+
+
+def ball_query(radius, nsample, xyz, new_xyz):
+    """-> (B,S,nsample) int32.  Inside QueryAndGroup, discriminator.py:190."""
+    _check_float(xyz, "xyz", 3)
+    _check_float(new_xyz, "new_xyz", 3)
+    _same_device(xyz, new_xyz)
+    _need(xyz.shape[0] == new_xyz.shape[0], "batch mismatch")
+    with torch.no_grad():
+        return backend_for(xyz).ball_query(float(radius), int(nsample), xyz.detach(), new_xyz.detach())
+
+
+class _Group(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, features, idx):
+        _check_float(features, "features", 3)
+        _check_int(idx, "idx", 3)
+        _same_device(features, idx)
+        _need(features.shape[0] == idx.shape[0], "batch mismatch")
+        ctx.save_for_backward(idx)
+        ctx.N = features.shape[2]
+        return backend_for(features).group_fwd(features, idx)
+
+    @staticmethod
+    def backward(ctx, grad_out):
+        (idx,) = ctx.saved_tensors
+        g = backend_for(grad_out).group_bwd(grad_out.contiguous().float(), idx, ctx.N)
+        return g, None
+
+
+def grouping_operation(features, idx):
+    """(B,C,N),(B,S,K) int32 -> (B,C,S,K).  gcn_lib/pointnet/gcn.py:207,261; discriminator.py:270,273."""
+    return _Group.apply(features, idx)
+
+
+def three_nn(unknown, known):
+    """-> (dist (B,n,3) = sqrt of squared distance, idx (B,n,3) int32)."""
+    _check_float(unknown, "unknown", 3)
+    _check_float(known, "known", 3)
+    _same_device(unknown, known)
+    with torch.no_grad():
+        d2, idx = backend_for(unknown).three_nn(unknown.detach(), known.detach())
+    return torch.sqrt(d2), idx
+
+
+class _ThreeInterpolate(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, features, idx, weight):
+        _check_float(features, "features", 3)
+        _check_int(idx, "idx", 3)
+        _check_float(weight, "weight", 3)
+        _same_device(features, idx, weight)
+        ctx.save_for_backward(idx, weight)
+        ctx.m = features.shape[2]
+        return backend_for(features).three_interp_fwd(features, idx, weight)
+
+    @staticmethod
+    def backward(ctx, grad_out):
+        idx, weight = ctx.saved_tensors
+        g = backend_for(grad_out).three_interp_bwd(grad_out.contiguous().float(), idx, weight, ctx.m)
+        return g, None, None
+
+
+def three_interpolate(features, idx, weight):
+    return _ThreeInterpolate.apply(features, idx, weight)
+
+
+# ------------------------------------------------------------- kNN / FRNN
+def _lengths(t, B, P, device):
+    if t is None:
+        return None
+    t = torch.as_tensor(t, device=device).to(torch.int64).contiguous()
+    _need(t.shape == (B,), "lengths must have shape (B,)")
+    return t
+
+
+def neighbour_search(p1, p2, K, lengths1=None, lengths2=None, r=None):
+    """Raw search: (dists (B,P1,K) f32, idx (B,P1,K) i64); r=None -> kNN, else d < r^2.
+
+    dists/idx carry no autograd history (callers add it, see knn_points)."""
+    _need(p1.dim() == 3 and p2.dim() == 3, "p1, p2 must be (B,P,D)")
+    _need(p1.shape[0] == p2.shape[0] and p1.shape[2] == p2.shape[2], "p1/p2 batch or dim mismatch")
+    _need(int(K) >= 1, "K must be >= 1")
+    _same_device(p1, p2)
+    a = p1.detach().float().contiguous()
+    b = p2.detach().float().contiguous()
+    B = a.shape[0]
+    l1 = _lengths(lengths1, B, a.shape[1], a.device)
+    l2 = _lengths(lengths2, B, b.shape[1], a.device)
+    r2 = None if r is None else radius_sq(r)
+    return backend_for(a).knn(a, b, l1, l2, int(K), r2)
+
+
+class _KnnDists(torch.autograd.Function):
+    """Attaches the analytic gradient of squared distances to searched dists."""
+
+    @staticmethod
+    def forward(ctx, p1, p2, dists, idx):
+        ctx.save_for_backward(p1, p2, idx)
+        return dists.clone()
+
+    @staticmethod
+    def backward(ctx, g):
+        p1, p2, idx = ctx.saved_tensors
+        B, P1, K = idx.shape
+        D = p1.shape[2]
+        valid = (idx >= 0)
+        safe = idx.clamp(min=0)
+        nb = torch.gather(p2.unsqueeze(1).expand(B, P1, p2.shape[1], D), 2,
+                          safe.unsqueeze(-1).expand(B, P1, K, D))
+        diff = (p1.unsqueeze(2) - nb) * (2.0 * g * valid).unsqueeze(-1)
+        g1 = diff.sum(2)
+        g2 = torch.zeros_like(p2)
+        g2.scatter_add_(1, safe.reshape(B, P1 * K, 1).expand(B, P1 * K, D), -diff.reshape(B, P1 * K, D))
+        return g1, g2, None, None
+
+
+def attach_dist_grad(p1, p2, dists, idx):
+    if torch.is_grad_enabled() and (p1.requires_grad or p2.requires_grad):
+        return _KnnDists.apply(p1.float(), p2.float(), dists, idx)
+    return dists
+
+
+# ------------------------------------------------------------------ Chamfer
+class _ChamferNN(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, src, tgt):
+        d1, i1, d2, i2 = backend_for(src).chamfer_fwd(src, tgt)
+        ctx.save_for_backward(src, tgt, i1, i2)
+        ctx.mark_non_differentiable(i1, i2)
+        return d1, d2, i1, i2
+
+    @staticmethod
+    def backward(ctx, g1, g2, _gi1, _gi2):
+        src, tgt, i1, i2 = ctx.saved_tensors
+        gs, gt = backend_for(src).chamfer_bwd(src, tgt, i1, i2, g1.contiguous().float(),
+                                              g2.contiguous().float())
+        return gs, gt
+
+
+def chamfer_nn(src, tgt):
+    """(B,N,3),(B,M,3) -> d1 (B,N), d2 (B,M), i1, i2; differentiable wrt both clouds."""
+    _need(src.dim() == 3 and tgt.dim() == 3 and src.shape[2] == 3 and tgt.shape[2] == 3,
+          "clouds must be (B,N,3)")
+    _need(src.shape[0] == tgt.shape[0], "batch mismatch")
+    _same_device(src, tgt)
+    return _ChamferNN.apply(src.float().contiguous(), tgt.float().contiguous())

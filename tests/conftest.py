@@ -1,0 +1,33 @@
+import os
+import sys
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+
+def pytest_configure(config):
+    config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
+
+
+@pytest.fixture(scope="session")
+def hip_lib():
+    """Build (if stale and hipcc exists) and load the C-ABI library."""
+    import tpgan_amd  # noqa: F401
+    from tpgan_amd import _lib
+    from tpgan_amd.build import build_hip, is_stale
+    if is_stale() and os.path.exists("/opt/rocm/bin/hipcc"):
+        build_hip()
+    return _lib.load()
+
+
+@pytest.fixture()
+def oracle_cpu():
+    """Register the oracle as the op backend for CPU tensors for one test."""
+    import tpgan_amd  # noqa: F401
+    from oracle import torch_backend
+    torch_backend.install()
+    yield
+    torch_backend.uninstall()

@@ -1,0 +1,77 @@
+"""The C-ABI library loads without a GPU and exports every symbol include/*.h declares;
+the product path refuses CPU tensors (no fallback) and never imports the oracle."""
+import glob
+import os
+import re
+import subprocess
+import sys
+
+import pytest
+import torch
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _declared_symbols():
+    names = set()
+    for h in glob.glob(os.path.join(ROOT, "include", "*.h")):
+        txt = re.sub(r"/\*.*?\*/", "", open(h).read(), flags=re.S)
+        names |= set(re.findall(r"\b(tpg_[a-z0-9_]+)\s*\(", txt))
+    return names
+
+
+def test_header_declares_the_whole_boundary():
+    names = _declared_symbols()
+    for need in ["tpg_knn_f32", "tpg_chamfer_fwd_f32", "tpg_chamfer_bwd_f32", "tpg_fps_f32",
+                 "tpg_gather_fwd_f32", "tpg_gather_bwd_f32", "tpg_ball_query_f32",
+                 "tpg_group_fwd_f32", "tpg_group_bwd_f32", "tpg_three_nn_f32",
+                 "tpg_three_interp_fwd_f32", "tpg_three_interp_bwd_f32"]:
+        assert need in names
+
+
+def test_library_exports_every_declared_symbol(hip_lib):
+    from tpgan_amd import _lib
+    for name in _declared_symbols():
+        assert hasattr(hip_lib, name), f"{name} declared in include/ but not exported"
+    assert set(_lib.SIGNATURES) | set(_lib.STRING_GETTERS) == _declared_symbols()
+    assert hip_lib.tpg_target_arch() == b"gfx950"
+
+
+def test_code_object_targets_gfx950(hip_lib):
+    from tpgan_amd import _lib
+    blob = open(_lib.LIB_PATH, "rb").read()
+    assert b"gfx950" in blob and b"gfx942" not in blob and b"sm_" not in blob
+
+
+def test_cpu_tensors_are_refused_without_a_registered_checker():
+    import tpgan_amd.ops as ops
+    ops.unregister_backend("cpu")
+    with pytest.raises(RuntimeError, match="no CPU fallback"):
+        ops.furthest_point_sample(torch.zeros(1, 8, 3), 4)
+    with pytest.raises(RuntimeError, match="no CPU fallback"):
+        ops.grouping_operation(torch.zeros(1, 2, 8), torch.zeros(1, 4, 2, dtype=torch.int32))
+
+
+def test_product_package_never_imports_the_oracle():
+    code = ("import sys; sys.path.insert(0, %r); import tpgan_amd, tpgan_amd.ops; "
+            "tpgan_amd.install_compat(); import pointnet2_ops.pointnet2_utils, pytorch3d.ops, frnn, "
+            "chamferdist; import tpgan_amd.gan_step; "
+            "bad=[m for m in sys.modules if m == 'oracle' or m.startswith('oracle.')]; "
+            "assert not bad, bad") % ROOT
+    subprocess.check_call([sys.executable, "-c", code])
+    pkg = os.path.join(ROOT, "temporal-pointcloud-upsampling-gan_amd")
+    for path in glob.glob(os.path.join(pkg, "**", "*.py"), recursive=True):
+        src = open(path).read()
+        assert not re.search(r"^\s*(from|import)\s+oracle\b", src, flags=re.M), path
+
+
+def test_validation_errors_match_upstream_style(oracle_cpu):
+    import tpgan_amd.ops as ops
+    f = torch.zeros(1, 2, 8)
+    with pytest.raises(RuntimeError, match="int tensor"):
+        ops.grouping_operation(f, torch.zeros(1, 4, 2, dtype=torch.int64))
+    with pytest.raises(RuntimeError, match="contiguous"):
+        ops.grouping_operation(f.transpose(1, 2).contiguous().transpose(1, 2),
+                               torch.zeros(1, 4, 2, dtype=torch.int32))
+    with pytest.raises(RuntimeError, match="float tensor"):
+        ops.furthest_point_sample(torch.zeros(1, 8, 3, dtype=torch.float64), 4)

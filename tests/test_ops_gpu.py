@@ -1,0 +1,250 @@
+"""Parity tests proper: every HIP entry point, called through the C-ABI, against the
+oracle on the same seeded inputs.  Neighbour / sample indices must be BIT-EXACT, distances
+produced by the canonical no-FMA sum must be bit-exact too; scatter-add gradients (LDS /
+global float atomics, order not fixed) are held to 1e-5."""
+import numpy as np
+import pytest
+import torch
+
+from oracle import ref_ops as R
+
+pytestmark = pytest.mark.gpu
+TOL = 1e-5  # fp32 feature / gradient tolerance stated by BASELINE.json north_star
+
+
+@pytest.fixture(scope="module")
+def hip():
+    import tpgan_amd.ops as ops
+    assert torch.cuda.is_available()
+    return ops.backend_for(torch.zeros(1, device="cuda"))
+
+
+def dev(a):
+    return torch.from_numpy(np.ascontiguousarray(a)).cuda()
+
+
+def fluid(rng, B, N, scale=0.25):
+    return rng.uniform(-scale, scale, (B, N, 3)).astype(np.float32)
+
+
+# ------------------------------------------------------------------ kNN
+@pytest.mark.parametrize("B,P1,P2,D,K", [
+    (2, 512, 512, 3, 20), (2, 512, 512, 32, 9), (2, 512, 512, 32, 20), (2, 512, 512, 64, 12),
+    (2, 512, 512, 64, 4), (2, 512, 512, 64, 8), (3, 256, 256, 3, 32), (1, 100, 333, 5, 7),
+    (1, 70, 129, 16, 64), (2, 33, 4096, 3, 16), (1, 5, 3, 3, 8), (1, 64, 64, 3, 1)])
+def test_knn_bit_exact(hip, B, P1, P2, D, K):
+    rng = np.random.default_rng(B * 1000 + P1 + D + K)
+    p1 = rng.standard_normal((B, P1, D)).astype(np.float32)
+    p2 = p1.copy() if P1 == P2 else rng.standard_normal((B, P2, D)).astype(np.float32)
+    if P2 > 20:
+        p2[0, 5] = p2[0, 7]; p2[-1, 10:14] = p2[-1, 3]   # exact duplicates
+    d, i = hip.knn(dev(p1), dev(p2), None, None, K, None)
+    rd, ri = R.knn(p1, p2, K)
+    assert np.array_equal(i.cpu().numpy(), ri)
+    assert np.array_equal(d.cpu().numpy(), rd)
+
+
+def test_knn_all_identical_points(hip):
+    p = np.full((1, 200, 3), 999.0, np.float32)   # a cloud of hard-masking dummies
+    d, i = hip.knn(dev(p), dev(p), None, None, 16, None)
+    rd, ri = R.knn(p, p, 16)
+    assert np.array_equal(i.cpu().numpy(), ri) and np.array_equal(d.cpu().numpy(), rd)
+
+
+def test_knn_sorted_descending_worst_case(hip):
+    # candidates arrive in strictly decreasing distance: every candidate is inserted
+    x = np.zeros((1, 300, 3), np.float32)
+    x[0, :, 0] = np.linspace(30, 0.1, 300)
+    q = np.zeros((1, 4, 3), np.float32)
+    d, i = hip.knn(dev(q), dev(x), None, None, 20, None)
+    rd, ri = R.knn(q, x, 20)
+    assert np.array_equal(i.cpu().numpy(), ri) and np.array_equal(d.cpu().numpy(), rd)
+
+
+def test_knn_ragged(hip):
+    rng = np.random.default_rng(4)
+    p1, p2 = fluid(rng, 3, 40), fluid(rng, 3, 130)
+    l1, l2 = np.array([40, 7, 0]), np.array([130, 4, 65])
+    d, i = hip.knn(dev(p1), dev(p2), dev(l1), dev(l2), 6, None)
+    rd, ri = R.knn(p1, p2, 6, l1, l2)
+    assert np.array_equal(i.cpu().numpy(), ri) and np.array_equal(d.cpu().numpy(), rd)
+
+
+@pytest.mark.parametrize("B,P1,P2,K,r", [
+    (2, 512, 4096, 1, 0.0475), (2, 4096, 4096, 16, 0.035), (3, 256, 256, 32, 2.0),
+    (1, 100, 300, 8, 0.01), (1, 64, 64, 64, 0.2)])
+def test_frnn_bit_exact(hip, B, P1, P2, K, r):
+    import tpgan_amd.ops as ops
+    rng = np.random.default_rng(K)
+    p2 = fluid(rng, B, P2)
+    p1 = p2.copy() if P1 == P2 else fluid(rng, B, P1)
+    d, i = hip.knn(dev(p1), dev(p2), None, None, K, ops.radius_sq(r))
+    rd, ri = R.knn(p1, p2, K, r=r)
+    assert np.array_equal(i.cpu().numpy(), ri)
+    assert np.array_equal(d.cpu().numpy(), rd)
+    assert ((ri == -1).any()) or r >= 0.2   # the small radii really exercise the -1 padding
+
+
+# ------------------------------------------------------------------ Chamfer
+@pytest.mark.parametrize("B,N,M", [(2, 4096, 4096), (3, 500, 777), (1, 1, 1), (2, 65, 64)])
+def test_chamfer_fwd_bit_exact_bwd_close(hip, B, N, M):
+    rng = np.random.default_rng(N + M)
+    s, t = fluid(rng, B, N), fluid(rng, B, M)
+    d1, i1, d2, i2 = hip.chamfer_fwd(dev(s), dev(t))
+    r1, ri1, r2, ri2 = R.chamfer_fwd(s, t)
+    assert np.array_equal(i1.cpu().numpy(), ri1) and np.array_equal(i2.cpu().numpy(), ri2)
+    assert np.array_equal(d1.cpu().numpy(), r1) and np.array_equal(d2.cpu().numpy(), r2)
+    g1 = rng.standard_normal((B, N)).astype(np.float32)
+    g2 = rng.standard_normal((B, M)).astype(np.float32)
+    gs, gt = hip.chamfer_bwd(dev(s), dev(t), i1, i2, dev(g1), dev(g2))
+    rs, rt = R.chamfer_bwd(s, t, ri1, ri2, g1, g2)
+    scale = max(1.0, np.abs(rs).max(), np.abs(rt).max())
+    assert np.abs(gs.cpu().numpy() - rs).max() <= TOL * scale
+    assert np.abs(gt.cpu().numpy() - rt).max() <= TOL * scale
+
+
+# ------------------------------------------------------------------ FPS
+@pytest.mark.parametrize("B,N,m", [
+    (2, 4096, 1024), (3, 1024, 512), (2, 1024, 256), (2, 512, 128), (2, 200, 64), (1, 64, 64),
+    (2, 2048, 512), (1, 5000, 300), (1, 9000, 200), (1, 20000, 64), (1, 10, 25), (4, 1, 3)])
+def test_fps_bit_exact(hip, B, N, m):
+    rng = np.random.default_rng(N + m)
+    x = fluid(rng, B, N)
+    if N > 8:
+        x[0, 3] = 0.0                 # origin point: skipped
+        x[-1, N // 2: N // 2 + 3] = 999.0   # dummies with identical coordinates
+    idx = hip.fps(dev(x), m)
+    assert idx.dtype == torch.int32
+    assert np.array_equal(idx.cpu().numpy(), R.fps(x, m))
+
+
+def test_fps_all_points_inside_origin_ball(hip):
+    x = np.full((2, 300, 3), 0.01, np.float32)
+    assert np.array_equal(hip.fps(dev(x), 16).cpu().numpy(), R.fps(x, 16))
+
+
+def test_fps_duplicate_points_tie_to_smallest_index(hip):
+    rng = np.random.default_rng(0)
+    x = fluid(rng, 1, 128)
+    x = np.concatenate([x, x], axis=1)   # every point twice (MSR-style repeats)
+    assert np.array_equal(hip.fps(dev(x), 100).cpu().numpy(), R.fps(x, 100))
+
+
+# ------------------------------------------------------------------ ball query
+@pytest.mark.parametrize("B,N,S,r,ns", [
+    (2, 4096, 1024, 0.10, 32), (2, 4096, 1024, 0.15, 32), (2, 1024, 512, 0.30, 32),
+    (2, 512, 128, 0.60, 16), (2, 1024, 256, 0.20, 32), (1, 2048, 512, 0.8, 64),
+    (1, 9000, 77, 0.05, 16), (1, 100, 3, 0.001, 8), (3, 70, 70, 0.2, 100)])
+def test_ball_query_bit_exact(hip, B, N, S, r, ns):
+    rng = np.random.default_rng(N + S + ns)
+    x = fluid(rng, B, N)
+    q = x[:, rng.permutation(N)[:S]].copy()
+    if S > 2:
+        q[0, 1] = 50.0    # a query with no neighbour at all -> zero row
+    idx = hip.ball_query(r, ns, dev(x), dev(q))
+    assert idx.dtype == torch.int32
+    assert np.array_equal(idx.cpu().numpy(), R.ball_query(r, ns, x, q))
+
+
+# ------------------------------------------------------------------ group / gather
+@pytest.mark.parametrize("B,C,N,S,K", [
+    (2, 3, 512, 512, 20), (2, 32, 512, 512, 9), (2, 64, 512, 512, 12), (2, 128, 1024, 512, 32),
+    (2, 256, 256, 256, 32), (2, 3, 4096, 1024, 32), (1, 5, 100, 33, 7), (1, 1, 1, 1, 1),
+    (1, 9, 6000, 50, 3), (1, 2, 20000, 10, 4)])
+def test_group_fwd_exact_bwd_close(hip, B, C, N, S, K):
+    rng = np.random.default_rng(C + N + S + K)
+    f = rng.standard_normal((B, C, N)).astype(np.float32)
+    idx = rng.integers(0, N, (B, S, K)).astype(np.int32)
+    idx[0, 0, :] = 0   # heavy repetition on one row
+    out = hip.group_fwd(dev(f), dev(idx))
+    assert np.array_equal(out.cpu().numpy(), R.group_fwd(f, idx))
+    g = rng.standard_normal((B, C, S, K)).astype(np.float32)
+    gf = hip.group_bwd(dev(g), dev(idx), N).cpu().numpy()
+    ref = R.group_bwd(g, idx, N)
+    assert np.abs(gf - ref).max() <= TOL * max(1.0, np.abs(ref).max())
+
+
+def test_group_bwd_is_deterministic_for_permutation_indices(hip):
+    # every source index used exactly once -> no accumulation order -> bit-exact
+    rng = np.random.default_rng(1)
+    N = 512
+    idx = np.stack([rng.permutation(N) for _ in range(2)]).astype(np.int32).reshape(2, N // 8, 8)
+    g = rng.standard_normal((2, 16, N // 8, 8)).astype(np.float32)
+    assert np.array_equal(hip.group_bwd(dev(g), dev(idx), N).cpu().numpy(), R.group_bwd(g, idx, N))
+
+
+@pytest.mark.parametrize("B,C,N,S", [(2, 3, 4096, 1024), (2, 3, 1024, 256), (1, 7, 50, 300), (1, 1, 1, 1)])
+def test_gather_fwd_exact_bwd_close(hip, B, C, N, S):
+    rng = np.random.default_rng(N + S)
+    f = rng.standard_normal((B, C, N)).astype(np.float32)
+    idx = rng.integers(0, N, (B, S)).astype(np.int32)
+    assert np.array_equal(hip.gather_fwd(dev(f), dev(idx)).cpu().numpy(), R.gather_fwd(f, idx))
+    g = rng.standard_normal((B, C, S)).astype(np.float32)
+    ref = R.gather_bwd(g, idx, N)
+    got = hip.gather_bwd(dev(g), dev(idx), N).cpu().numpy()
+    assert np.abs(got - ref).max() <= TOL * max(1.0, np.abs(ref).max())
+
+
+def test_out_of_range_indices_never_fault(hip):
+    f = torch.arange(10, dtype=torch.float32, device="cuda").view(1, 1, 10).contiguous()
+    idx = torch.tensor([[[-5, 3, 10, 1 << 30]]], dtype=torch.int32, device="cuda")
+    out = hip.group_fwd(f, idx)
+    assert out.view(-1).tolist() == [9.0, 3.0, 9.0, 9.0]   # clamped, documented in DESIGN.md
+
+
+# ------------------------------------------------------------------ three_nn / interpolate
+def test_three_nn_and_interpolate(hip):
+    rng = np.random.default_rng(6)
+    u, k = fluid(rng, 2, 300), fluid(rng, 2, 500)
+    d2, idx = hip.three_nn(dev(u), dev(k))
+    rd, ri = R.three_nn(u, k)
+    assert np.array_equal(idx.cpu().numpy(), ri) and np.array_equal(d2.cpu().numpy(), rd)
+    f = rng.standard_normal((2, 6, 500)).astype(np.float32)
+    w = rng.uniform(0, 1, (2, 300, 3)).astype(np.float32)
+    out = hip.three_interp_fwd(dev(f), idx, dev(w)).cpu().numpy()
+    assert np.array_equal(out, R.three_interp_fwd(f, ri, w))
+    g = rng.standard_normal(out.shape).astype(np.float32)
+    ref = R.three_interp_bwd(g, ri, w, 500)
+    got = hip.three_interp_bwd(dev(g), idx, dev(w), 500).cpu().numpy()
+    assert np.abs(got - ref).max() <= TOL * max(1.0, np.abs(ref).max())
+
+
+# ------------------------------------------------------------------ full-size properties
+def test_full_size_properties_cfg2(hip):
+    """BASELINE config 2 sizes (B=8, N_hi=4096): size-independent properties, no oracle."""
+    g = torch.Generator(device="cpu").manual_seed(1234)
+    x = (torch.rand(8, 4096, 3, generator=g) - 0.5) * 0.5
+    xd = x.cuda()
+    # kNN: self is neighbour 0 at distance 0, rows sorted ascending, indices unique per row
+    d, i = hip.knn(xd, xd, None, None, 16, None)
+    assert torch.equal(i[:, :, 0], torch.arange(4096, device="cuda").expand(8, -1))
+    assert (d[:, :, 0] == 0).all() and (d[:, :, 1:] >= d[:, :, :-1]).all()
+    assert (torch.sort(i, dim=2)[0][:, :, 1:] != torch.sort(i, dim=2)[0][:, :, :-1]).all()
+    # FRNN == kNN wherever the k-th neighbour lies inside the radius
+    import tpgan_amd.ops as ops
+    fd, fi = hip.knn(xd, xd, None, None, 16, ops.radius_sq(0.035))
+    inside = d < ops.radius_sq(0.035)
+    assert torch.equal(fi[inside], i[inside]) and (fi[~inside] == -1).all()
+    # FPS: indices distinct, first is 0
+    s = hip.fps(xd, 1024)
+    assert (s[:, 0] == 0).all()
+    assert all(len(set(row.tolist())) == 1024 for row in s.cpu())
+    # ball query rows: sorted ascending until the fill, all within radius
+    new = torch.gather(xd, 1, s.long().unsqueeze(-1).expand(-1, -1, 3)).contiguous()
+    bq = hip.ball_query(0.15, 32, xd, new)
+    nb = torch.gather(xd.unsqueeze(1).expand(-1, 1024, -1, -1), 2,
+                      bq.long().unsqueeze(-1).expand(-1, -1, -1, 3))
+    assert (((nb - new.unsqueeze(2)) ** 2).sum(-1) < 0.15 ** 2 + 1e-6).all()
+    # group: linear in the features, and group(bwd(ones)) counts index multiplicities
+    f = torch.randn(8, 128, 4096, device="cuda")
+    o = hip.group_fwd(f, bq)
+    assert torch.equal(o, torch.gather(f.unsqueeze(2).expand(-1, -1, 1024, -1), 3,
+                                       bq.long().unsqueeze(1).expand(-1, 128, -1, -1)))
+    cnt = hip.group_bwd(torch.ones(8, 1, 1024, 32, device="cuda"), bq, 4096)
+    ref = torch.zeros(8, 4096, device="cuda").scatter_add_(1, bq.long().view(8, -1),
+                                                           torch.ones(8, 1024 * 32, device="cuda"))
+    assert torch.equal(cnt[:, 0], ref)
+    # Chamfer of a cloud with itself is exactly 0 with identity assignment
+    d1, i1, d2, i2 = hip.chamfer_fwd(xd, xd)
+    assert (d1 == 0).all() and (d2 == 0).all()
+    assert torch.equal(i1, torch.arange(4096, device="cuda").expand(8, -1))
