@@ -1,0 +1,82 @@
+"""Data-parallel sharding of the adversarial step: one process per GPU, RCCL over xGMI.
+
+The reference has no distributed code at all; this is the build's
+own design for BASELINE configs 3/5.  The batch is sharded over the ranks (every op and
+module on the path is per-cloud; BatchNorm statistics stay per-rank like stock DDP).  The
+only exchanges per step are
+
+  * one 4-byte all-reduce of the gate statistic `ml`, so all ranks take the same branch;
+  * ONE all-reduce per optimizer step on a flat fp32 bucket holding every gradient of
+    that network (G 1.77 MB, D_tempo 2.95 MB, D_spatial 1.23 MB): at these sizes a
+    fully-connected xGMI mesh is latency-bound, so one launch per step beats per-tensor
+    hooks, and there is no bucket to tune.
+
+Backend "nccl" is RCCL on ROCm; "gloo" is used by the CPU tests.
+"""
+import os
+
+import torch
+import torch.distributed as dist
+
+
+def init_from_env(backend=None):
+    """Join the process group described by RANK/WORLD_SIZE/MASTER_* (torch.distributed.run).
+
+    Returns (rank, world_size, local_rank).  Safe to call in a single-process run."""
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local = int(os.environ.get("LOCAL_RANK", "0"))
+    if world > 1 and not dist.is_initialized():
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        if backend is None:
+            backend = "nccl" if torch.cuda.is_available() else "gloo"
+        if backend == "nccl":
+            torch.cuda.set_device(local)
+        dist.init_process_group(backend=backend, rank=rank, world_size=world)
+    return rank, world, local
+
+
+class GradSync:
+    """Gate + gradient averaging over a process group (no-ops when world_size == 1)."""
+
+    def __init__(self, group=None):
+        self.group = group
+        self.world_size = dist.get_world_size(group) if dist.is_initialized() else 1
+
+    def gate_value(self, ml):
+        """Mean of the per-rank masking loss: every rank then evaluates the same `ml < 0.1`."""
+        if self.world_size == 1:
+            return ml
+        v = ml.detach().float().reshape(-1)[:1].clone()
+        dist.all_reduce(v, op=dist.ReduceOp.SUM, group=self.group)
+        return v / self.world_size
+
+    def average_grads(self, module):
+        """Average every existing .grad of `module` with one flat all-reduce."""
+        if self.world_size == 1:
+            return
+        grads = [p.grad for p in module.parameters() if p.grad is not None]
+        if not grads:
+            return
+        flat = torch.cat([g.reshape(-1) for g in grads])
+        dist.all_reduce(flat, op=dist.ReduceOp.SUM, group=self.group)
+        flat.div_(self.world_size)
+        off = 0
+        for g in grads:
+            n = g.numel()
+            g.copy_(flat[off:off + n].view_as(g))
+            off += n
+
+    def broadcast_state(self, *modules, src=0):
+        """Make parameters AND buffers (BN stats, spectral-norm u/v) identical at start."""
+        if self.world_size == 1:
+            return
+        for m in modules:
+            for t in list(m.parameters()) + list(m.buffers()):
+                dist.broadcast(t.data, src=src, group=self.group)
+
+
+def barrier():
+    if dist.is_initialized():
+        dist.barrier()

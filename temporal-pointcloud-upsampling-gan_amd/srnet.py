@@ -39,12 +39,13 @@ class GCNFeatureExtractor(nn.Module):
         return torch.cat(outs, dim=1)                              # (B,C',N,1)
 
 
-def _head_layers(width, last_edgeconv):
+def _head_layers(width, make_last_edgeconv):
+    # modules are created in forward order so that seeded initialisation matches the reference
     layers = nn.ModuleList()
     layers.append(conv_bn_layer(width, width // 4, norm="none"))
     layers.append(EdgeConv(width // 4, width, aggregate="max", mlp_layer=True, k=12, bn=False, insn=False))
     layers.append(conv_bn_layer(width, width // 4, norm="none"))
-    layers.append(last_edgeconv)
+    layers.append(make_last_edgeconv())
     return layers
 
 
@@ -57,7 +58,7 @@ class UpsamplingModule(nn.Module):
         self.upsample_ratio = upsample_ratio
         w = in_node_feat_dim
         self.upsample_layers = _head_layers(
-            w, EdgeConv(w // 4, w, aggregate="max", mlp_layer=True, k=4, bn=False, insn=False))
+            w, lambda: EdgeConv(w // 4, w, aggregate="max", mlp_layer=True, k=4, bn=False, insn=False))
         self.decoder = nn.Sequential(
             build_shared_mlp([w, out_dim // 2, out_dim], norm="none"),
             nn.Conv2d(out_dim, out_dim, 1, 1, 0, bias=True))
@@ -75,7 +76,7 @@ class BinaryMaskingModule(nn.Module):
             raise NotImplementedError("the reference only ever builds gcn_layer=2")
         w = in_node_feat_dim
         self.upsample_layers = _head_layers(
-            w, EdgeConv(w // 4, w, aggregate="sum", mlp_layer=False, k=8, bn=False, insn=False))
+            w, lambda: EdgeConv(w // 4, w, aggregate="sum", mlp_layer=False, k=8, bn=False, insn=False))
         self.decoder = nn.Sequential(
             build_shared_mlp([w, w // 2, w // 4], norm="none"),
             nn.Conv2d(w // 4, 1, 1, 1, 0, bias=True))
@@ -98,6 +99,8 @@ class SRNet(nn.Module):
         self.filter_block = BinaryMaskingModule(width)
         self.upsample_ratio = upsample_ratio
         self.epsilon = 0.01
+        # per frame of the most recent forward/forward_frames: did hard masking pad with 999?
+        self.last_pad_flags = []
 
     # -- network body: everything up to (offsets, mask); batch rows are independent ----------
     def body(self, feature, pos):
@@ -111,6 +114,7 @@ class SRNet(nn.Module):
         keep = binary_mask.detach().view(B, -1, 1) > self.epsilon
         edge = upsample_edge * keep.float()
         expanded = pos.repeat(1, 1, r).view(B, -1, 3) + edge.view(B, -1, 3)
+        self._padded = False
         if not hard_masking:
             return expanded, None
         hard = keep.repeat(1, 1, r)
@@ -120,12 +124,14 @@ class SRNet(nn.Module):
         if B > 1 and bool(torch.any(counts != counts.max())):      # host decision, as upstream
             padded = expanded.clone()
             padded[~hard] = 999
+            self._padded = True
             return expanded, padded
         return expanded, expanded[hard].view(B, -1, 3)
 
     def forward(self, feature, pos, hard_masking=False):
         edge, mask = self.body(feature, pos)
         out_pos, padded = self.expand_pos_with_masking(pos, edge, mask, hard_masking=hard_masking)
+        self.last_pad_flags = [self._padded]
         return out_pos, mask, padded
 
     def forward_frames(self, features, positions, hard_masking=False):
@@ -135,11 +141,13 @@ class SRNet(nn.Module):
         per frame exactly as T separate `forward` calls would (upsampling_network.py:147)."""
         T, B = len(positions), positions[0].shape[0]
         edge, mask = self.body(torch.cat(features, 0), torch.cat(positions, 0))
-        outs = []
+        outs, flags = [], []
         for t in range(T):
             sl = slice(t * B, (t + 1) * B)
             p, padded = self.expand_pos_with_masking(positions[t], edge[sl], mask[sl], hard_masking)
             outs.append((p, mask[sl], padded))
+            flags.append(self._padded)
+        self.last_pad_flags = flags
         return outs
 
     def forward_with_context(self, feature, pos, previous_mask):

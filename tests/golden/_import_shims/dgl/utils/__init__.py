@@ -1,0 +1,3 @@
+from _inert import Inert
+def __getattr__(name):
+    return Inert("dgl.utils." + name)

@@ -1,0 +1,256 @@
+"""Generates tests/golden/*.npz by running the REFERENCE's own Python in the build container.
+
+    python tests/golden/capture_goldens.py            # writes the fixtures next to this file
+
+What runs: `/root/reference` (read-only, imported unmodified; never copied, never shipped)
+with `pointnet2_ops`, `pytorch3d`, `frnn`, `chamferdist` resolved to this repo's
+import-compatible modules, whose CPU tensors are served by the oracle (oracle/tpgref.c).
+`dgl`, `numba`, `open3d`, `emd` are inert import shims (tests/golden/_import_shims).
+`Tensor.cuda()` / `Module.cuda()` are patched to identity because the reference hard-codes
+`.cuda()` (loss.py:174, train_step_final.py:30,156-157).
+
+What is stored: inputs and expected outputs only (arrays), plus per-tensor checksums of the
+seeded random weights so the tests can prove that the build's modules, constructed under
+the same seed, hold bit-identical parameters under identical names.  The reference has no
+pretrained checkpoints (.MISSING_LARGE_BLOBS) and no fixtures of its own.
+
+This script cannot run on the GPU box (there is no /root/reference there); the tests only
+read the committed .npz files.
+"""
+import os
+import sys
+import warnings
+from argparse import Namespace
+
+import numpy as np
+import torch
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+ROOT = os.path.dirname(os.path.dirname(HERE))
+REFERENCE = "/root/reference"
+
+sys.dont_write_bytecode = True
+sys.path.insert(0, ROOT)
+sys.path.insert(0, os.path.join(HERE, "_import_shims"))
+
+import tpgan_amd  # noqa: E402
+
+tpgan_amd.install_compat()
+sys.path.insert(2, REFERENCE)
+from oracle import torch_backend  # noqa: E402
+
+torch_backend.install()
+torch.Tensor.cuda = lambda self, *a, **k: self
+torch.nn.Module.cuda = lambda self, *a, **k: self
+warnings.simplefilter("ignore")
+
+import discriminator as ref_dis  # noqa: E402
+import loss as ref_loss  # noqa: E402
+import train_step_final as ref_step  # noqa: E402
+import upsampling_network as ref_net  # noqa: E402
+
+from tpgan_amd.synthetic import action_clip, fluid_clip  # noqa: E402
+
+torch.set_num_threads(8)
+
+
+def checksums(module):
+    """name -> (sum, abs-sum) in float64 for every state-dict entry."""
+    out = {}
+    for k, v in module.state_dict().items():
+        v = v.detach().double()
+        out[k] = np.array([v.sum().item(), v.abs().sum().item(), float(v.numel())])
+    return out
+
+
+def pack(prefix, d):
+    return {f"{prefix}/{k}": v for k, v in d.items()}
+
+
+def save(name, **arrays):
+    path = os.path.join(HERE, name + ".npz")
+    np.savez_compressed(path, **{k: np.asarray(v) for k, v in arrays.items()})
+    print(f"{name}: {os.path.getsize(path) / 1024:.0f} KiB, {len(arrays)} arrays")
+
+
+def n(t):
+    return t.detach().cpu().numpy()
+
+
+def set_mask_head(net, mode, seed):
+    """all-keep: mask == 1.  mixed: mask values straddle epsilon = 0.01 (pads with 999)."""
+    last = net.filter_block.decoder[1]
+    with torch.no_grad():
+        if mode == "keep":
+            last.weight.zero_()
+            last.bias.fill_(1.0)
+        elif mode == "mixed":
+            g = torch.Generator().manual_seed(seed)
+            last.weight.copy_(30.0 * torch.randn(last.weight.shape, generator=g))
+            last.bias.fill_(-0.01)
+
+
+# ----------------------------------------------------------------------------- generator
+def capture_generator():
+    out = {}
+    torch.manual_seed(11)
+    net = ref_net.SRNet(3, 128)
+    out.update(pack("w", checksums(net)))
+    low, _ = fluid_clip(2, 1024, 8, 1, seed=5)
+    x = low[0]
+    out["x"] = n(x)
+    for mode in ("init", "keep", "mixed"):
+        set_mask_head(net, mode, 3)
+        for hard in (False, True):
+            pos, mask, padded = net(x, x, hard_masking=hard)
+            tag = f"{mode}/{'hard' if hard else 'soft'}"
+            out[f"{tag}/pos"] = n(pos)
+            out[f"{tag}/mask"] = n(mask)
+            if padded is not None:
+                out[f"{tag}/padded"] = n(padded)
+    # six input features: kNN of the first layer runs on pos (upsampling_network.py:177-180)
+    torch.manual_seed(12)
+    net6 = ref_net.SRNet(6, 128)
+    out.update(pack("w6", checksums(net6)))
+    set_mask_head(net6, "keep", 0)
+    f6 = torch.cat([x, 0.1 * torch.randn(x.shape, generator=torch.Generator().manual_seed(2))], dim=2)
+    out["f6"] = n(f6)
+    pos, mask, _ = net6(f6, x, hard_masking=False)
+    out["six/pos"], out["six/mask"] = n(pos), n(mask)
+    # rollout with context (upsampling_network.py:159-174)
+    set_mask_head(net, "keep", 0)
+    hist = []
+    p1, hist = net.forward_with_context(x[:1], x[:1], hist)
+    p2, hist = net.forward_with_context(x[1:], x[1:], hist)
+    out["ctx/p1"], out["ctx/p2"] = n(p1), n(p2)
+    save("generator_srnet", **out)
+
+    out = {}
+    torch.manual_seed(13)
+    net = ref_net.NoMaskSRNet(3, 128, upsample_ratio=16)
+    out.update(pack("w", checksums(net)))
+    low, _ = action_clip(2, 2048, 16, 1, seed=6)
+    out["x"] = n(low[0])
+    pos, edge = net(low[0], low[0])
+    out["pos"], out["edge"] = n(pos), n(edge)
+    save("generator_nomask", **out)
+
+
+# ------------------------------------------------------------------------- discriminators
+def capture_discriminators():
+    _, high = fluid_clip(2, 1024, 8, 3, seed=7)
+    _, ahigh = action_clip(2, 1024, 16, 3, seed=8)
+    out = {"fluid": np.stack([n(h) for h in high]), "action": np.stack([n(h) for h in ahigh])}
+    specs = [("fluid_spatial", lambda: ref_dis.FluidSpatialDis(), lambda m: m(high[1])),
+             ("fluid_tempo", lambda: ref_dis.FluidTempoDis(3), lambda m: m(list(high), 0.10)),
+             ("action_spatial", lambda: ref_dis.ActionSpatialDis(), lambda m: m(ahigh[1])),
+             ("action_tempo", lambda: ref_dis.ActionTempoDis(3), lambda m: m(list(ahigh), 2.0))]
+    for i, (name, make, run) in enumerate(specs):
+        torch.manual_seed(20 + i)
+        m = make()
+        out.update(pack(f"{name}/w", checksums(m)))
+        m.train()
+        torch.manual_seed(100 + i)          # dropout draws
+        out[f"{name}/train"] = n(run(m))
+        out.update(pack(f"{name}/w_after", checksums(m)))   # BN running stats, spectral-norm u/v
+        m.eval()
+        out[f"{name}/eval"] = n(run(m))
+    # padded clouds: FPS hits on 999-dummies are replaced (discriminator.py:115-130)
+    padded = high[1].clone()
+    padded[0, 700:] = 999
+    padded[1, 900:] = 999
+    out["padded"] = n(padded)
+    torch.manual_seed(24)
+    m = ref_dis.FluidSpatialDis()
+    m.eval()
+    np.random.seed(77)
+    out["fluid_spatial/padded_eval"] = n(m(padded))
+    # T = 5 frames: 10 FlowEmbedding calls
+    _, high5 = fluid_clip(1, 1024, 8, 5, seed=9)
+    out["fluid5"] = np.stack([n(h) for h in high5])
+    torch.manual_seed(25)
+    m = ref_dis.FluidTempoDis(5)
+    out.update(pack("fluid_tempo5/w", checksums(m)))
+    m.eval()
+    out["fluid_tempo5/eval"] = n(m(list(high5), 0.10))
+    # ball_query_wrapper with a radius small enough to leave -1 slots before the kNN fill
+    idx = ref_dis.ball_query_wrapper(0.04, 32, high[0][:, :256], high[1])
+    out["bqw/idx"] = n(idx)
+    save("discriminators", **out)
+
+
+# ------------------------------------------------------------------------------- losses
+def capture_losses():
+    low, high = fluid_clip(2, 1024, 8, 1, seed=10)
+    g = torch.Generator().manual_seed(4)
+    pred = (high[0] + 0.01 * torch.randn(high[0].shape, generator=g)).requires_grad_(True)
+    mask = torch.rand(2, 128, 1, generator=g).requires_grad_(True)
+    out = {"low": n(low[0]), "high": n(high[0]), "pred": n(pred), "mask": n(mask)}
+    for n_iter in (5, 12):
+        total, cd, ml = ref_loss.tpugan_sr_loss(100., high[0], pred, low[0], mask, 0.025, n_iter)
+        gp, gm = torch.autograd.grad(total, [pred, mask], allow_unused=True)
+        out[f"it{n_iter}/total"], out[f"it{n_iter}/cd"], out[f"it{n_iter}/ml"] = n(total), n(cd), n(ml)
+        out[f"it{n_iter}/grad_pred"] = n(gp)
+        if gm is not None:
+            out[f"it{n_iter}/grad_mask"] = n(gm)
+    out["cd_unbatched"] = n(ref_loss.chamfer_distance_loss(high[0][0], pred[0]))
+    save("losses", **out)
+
+
+# --------------------------------------------------------------------------- train steps
+def step_fixture(kind):
+    out = {}
+    if kind == "action":
+        torch.manual_seed(40)
+        G = ref_net.NoMaskSRNet(3, 128, upsample_ratio=16)
+        torch.manual_seed(41)
+        Ds = ref_dis.ActionSpatialDis()
+        torch.manual_seed(42)
+        Dt = ref_dis.ActionTempoDis(3)
+        low, high = action_clip(2, 2048, 16, 3, seed=30)
+        opt = Namespace(R=2.0, w=2.0)
+    else:
+        torch.manual_seed(30)
+        G = ref_net.SRNet(3, 128)
+        torch.manual_seed(31)
+        Ds = ref_dis.FluidSpatialDis()
+        torch.manual_seed(32)
+        Dt = ref_dis.FluidTempoDis(3)
+        if kind == "fluid_keep":
+            set_mask_head(G, "keep", 0)
+        low, high = fluid_clip(2, 1024, 8, 3, seed=31)
+        opt = Namespace(use_vel=False, in_node_feats=3, cutoff=0.025, R=0.10, w=0.5)
+    for tag, m in (("G", G), ("Ds", Ds), ("Dt", Dt)):
+        out.update(pack(f"w/{tag}", checksums(m)))
+    out["low"] = np.stack([n(x) for x in low])
+    out["high"] = np.stack([n(x) for x in high])
+    # plain SGD so that parameter deltas are proportional to the gradients being compared
+    og = torch.optim.SGD(G.parameters(), lr=0.05)
+    ot = torch.optim.SGD(Dt.parameters(), lr=0.05)
+    os_ = torch.optim.SGD(Ds.parameters(), lr=0.05)
+    torch.manual_seed(500)
+    np.random.seed(500)
+    if kind == "action":
+        losses = ref_step.tempo_gan_step_no_mask(G, Ds, Dt, list(low), list(high), opt, 12, og, ot, os_)
+    else:
+        losses = ref_step.tempo_gan_step(G, Ds, Dt, list(low), None, list(high), None, 1.0, opt, 12,
+                                         og, ot, os_)
+    for k, v in losses.items():
+        out[f"loss/{k}"] = np.float64(v)
+    for tag, m in (("G", G), ("Ds", Ds), ("Dt", Dt)):
+        out.update(pack(f"w_after/{tag}", checksums(m)))
+    print(kind, losses)
+    save(f"step_{kind}", **out)
+
+
+if __name__ == "__main__":
+    which = sys.argv[1:] or ["gen", "dis", "loss", "steps"]
+    if "gen" in which:
+        capture_generator()
+    if "dis" in which:
+        capture_discriminators()
+    if "loss" in which:
+        capture_losses()
+    if "steps" in which:
+        for kind in ("fluid_keep", "fluid_init", "action"):
+            step_fixture(kind)
