@@ -1,0 +1,176 @@
+"""Headline benchmark: GAN train-steps/s (full G+D adversarial step) on synthetic
+4096-point x 3-frame fluid clips, batch 8 per GPU (BASELINE.json configs[1]; weak scaling).
+
+    python bench.py --gpus 1 --steps 20 --warmup 3
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 \
+        --master-port P bench.py --gpus N --steps K --warmup W
+
+One "step" = `tempo_gan_step` semantics with generator AND both discriminators updated
+(even iteration > 10, gate open, all-keep mask regime -- SURVEY.md section 8d).  Inputs are
+resident in HBM before the timed region.  Rank 0 prints ONE JSON line.
+
+Extra legs (rank 0, N == 1 only):
+  roofline      the hand-written kernel with the largest share of kernel time, timed live
+                with HIP events on its launch stream inside a second run of the same steps;
+  cpu_baseline  the same step function on the host cores through the oracle ops (kind
+                "port": the reference has no CPU path for pointnet2_ops/FRNN), on a bounded
+                sample (4 clips instead of 8), scaled to the metric's unit.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+from argparse import Namespace
+
+import numpy as np
+import torch
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+import tpgan_amd  # noqa: E402
+from tpgan_amd import ddp, ops  # noqa: E402
+from tpgan_amd.gan_step import tempo_gan_step  # noqa: E402
+from tpgan_amd.set_abstraction import FluidSpatialDis, FluidTempoDis  # noqa: E402
+from tpgan_amd.srnet import SRNet  # noqa: E402
+from tpgan_amd.synthetic import fluid_clip, force_all_keep  # noqa: E402
+
+HBM_PEAK_GBPS = 8000.0   # MI355X spec, /opt/skills/guides/MI355X_MICROARCH.md
+OPT = Namespace(use_vel=False, in_node_feats=3, cutoff=0.025, R=0.10, w=0.5)
+
+
+def build(device, seed=1):
+    torch.manual_seed(seed)
+    G = force_all_keep(SRNet(3, 128)).to(device)
+    Ds = FluidSpatialDis().to(device)
+    Dt = FluidTempoDis(3).to(device)
+    lr = 3e-4
+    opts = (torch.optim.Adam(G.parameters(), lr=lr), torch.optim.Adam(Dt.parameters(), lr=0.33 * lr),
+            torch.optim.Adam(Ds.parameters(), lr=0.33 * lr))
+    return G, Ds, Dt, opts
+
+
+def run_steps(models, clips, n, sync, amp_dtype, start=0):
+    G, Ds, Dt, (og, ot, os_) = models
+    out = None
+    for i in range(n):
+        low, high = clips[(start + i) % len(clips)]
+        out = tempo_gan_step(G, Ds, Dt, low, None, high, None, 1.0, OPT, 12, og, ot, os_,
+                             sync=sync, amp_dtype=amp_dtype, force_gate=True)
+    return out
+
+
+def cpu_baseline(sample_batch, per_gpu_batch, n_hi):
+    """Time ONE step of the same workload on the host cores (oracle ops + CPU PyTorch)."""
+    from oracle import torch_backend
+    torch_backend.install()
+    try:
+        cores = os.cpu_count() or 1
+        torch.set_num_threads(cores)
+        np.random.seed(0)
+        models = build("cpu")
+        warm = [fluid_clip(2, 512, 8, 3, seed=7)]
+        run_steps(models, warm, 1, None, None)                      # page in / thread pools
+        clips = [fluid_clip(sample_batch, n_hi, 8, 3, seed=1234)]
+        t0 = time.perf_counter()
+        run_steps(models, clips, 1, None, None)
+        dt = time.perf_counter() - t0
+    finally:
+        torch_backend.uninstall()
+    return {"value": (sample_batch / per_gpu_batch) / dt, "unit": "steps/s", "cores": cores,
+            "kind": "port",
+            "sample": f"1 full G+D step on {sample_batch} clips of {n_hi} pts x3 frames "
+                      f"({dt:.1f} s), scaled by {sample_batch}/{per_gpu_batch} to the batch-"
+                      f"{per_gpu_batch} step; fp32; oracle C ops (OpenMP) + CPU PyTorch convs"}
+
+
+def roofline_leg(models, clips, steps, sync, amp_dtype):
+    timer = ops.OpTimer()
+    ops.set_timer(timer)
+    try:
+        run_steps(models, clips, steps, sync, amp_dtype)
+        torch.cuda.synchronize()
+    finally:
+        ops.set_timer(None)
+    summ = timer.summary()
+    name = max(summ, key=lambda k: summ[k]["total_ms"])
+    dom = summ[name]
+    roof = {"bound": "hbm", "kernel": name, "achieved": round(dom["gbps"], 2), "peak": HBM_PEAK_GBPS,
+            "unit": "GB/s", "frac": round(dom["gbps"] / HBM_PEAK_GBPS, 6), "traffic": None,
+            "avg_launch_us": round(dom["avg_us"], 2), "launches_per_step": dom["launches"] / steps,
+            "algorithmic_bytes_per_launch": int(dom["bytes_per_launch"])}
+    table = {k: {"launches_per_step": v["launches"] / steps, "ms_per_step": round(v["total_ms"] / steps, 4),
+                 "avg_us": round(v["avg_us"], 2), "GBps": round(v["gbps"], 1)} for k, v in summ.items()}
+    return roof, table
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--batch", type=int, default=8, help="clips per GPU")
+    ap.add_argument("--points", type=int, default=4096, help="high-res points per frame")
+    ap.add_argument("--dtype", choices=["bf16", "fp32"], default="bf16")
+    ap.add_argument("--no-extra", action="store_true", help="skip roofline and cpu_baseline legs")
+    ap.add_argument("--cpu-sample-batch", type=int, default=4)
+    args = ap.parse_args()
+
+    rank, world, local = ddp.init_from_env()
+    if world != args.gpus:
+        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run")
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs a GPU (the product has no CPU fallback)")
+    torch.cuda.set_device(local)
+    device = torch.device("cuda", local)
+    amp_dtype = torch.bfloat16 if args.dtype == "bf16" else None
+    sync = ddp.GradSync()
+
+    np.random.seed(1234 + rank)
+    models = build(device)
+    sync.broadcast_state(*models[:3])
+    clips = [fluid_clip(args.batch, args.points, 8, 3, seed=1234 + rank * 1000 + s, device=device)
+             for s in range(4)]
+
+    run_steps(models, clips, args.warmup, sync, amp_dtype)
+    ddp.barrier()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    last = run_steps(models, clips, args.steps, sync, amp_dtype, start=args.warmup)
+    torch.cuda.synchronize()
+    ddp.barrier()
+    dt = torch.tensor([time.perf_counter() - t0], device=device, dtype=torch.float64)
+    if world > 1:
+        torch.distributed.all_reduce(dt, op=torch.distributed.ReduceOp.MAX)
+    dt = float(dt.item())
+
+    line = {
+        "metric": "GAN train-steps/sec (G+D) on 4096-pt x3-frame clips",
+        "value": world * args.steps / dt, "unit": "steps/s", "n_gpus": world, "steps": args.steps,
+        "warmup": args.warmup, "ms_per_step": 1e3 * dt / args.steps, "higher_is_better": True,
+        "scaling": "weak", "vs_baseline": None, "dtype": args.dtype if args.dtype == "fp32" else "bf16",
+        "data": "synthetic",
+        "config": {"workload": f"cfg2: {args.points}-pt x3-frame fluid clips, batch {args.batch} per GPU, "
+                               "full G+D adversarial step (SRNet(3,128) + FluidTempoDis(3) + "
+                               "FluidSpatialDis, Adam), all-keep mask regime, gate open, even iteration",
+                   "per_gpu_batch": args.batch, "global_batch": args.batch * world,
+                   "value_definition": "batch-of-%d steps per second summed over ranks" % args.batch,
+                   "precision": "bf16 autocast on 1x1 convs/linears; coordinates, neighbour search, "
+                                "indices, Chamfer in fp32" if args.dtype == "bf16" else "fp32",
+                   "parallelism": f"dp{world}", "last_losses": last},
+    }
+    if rank == 0 and world == 1 and not args.no_extra:
+        roof, table = roofline_leg(models, clips, min(args.steps, 5), sync, amp_dtype)
+        line["roofline"] = roof
+        line["kernels"] = table
+        line["cpu_baseline"] = cpu_baseline(args.cpu_sample_batch, args.batch, args.points)
+    if rank == 0:
+        print(json.dumps(line), flush=True)
+    if torch.distributed.is_initialized():
+        torch.distributed.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

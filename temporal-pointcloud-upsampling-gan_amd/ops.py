@@ -18,6 +18,52 @@ from . import _lib
 _BACKENDS = {}
 
 
+class OpTimer:
+    """Per-kernel timing with HIP events recorded on the stream each kernel is launched on
+    (torch's current stream).  Used by bench.py for the roofline leg; off by default."""
+
+    def __init__(self):
+        self.pending = {}   # name -> [(start_evt, end_evt, algorithmic_bytes)]
+
+    def record(self, name, nbytes, stream_of, launch):
+        st = torch.cuda.current_stream(stream_of.device)
+        a = torch.cuda.Event(enable_timing=True)
+        b = torch.cuda.Event(enable_timing=True)
+        a.record(st)
+        out = launch()
+        b.record(st)
+        self.pending.setdefault(name, []).append((a, b, nbytes))
+        return out
+
+    def summary(self):
+        """name -> dict(launches, total_ms, avg_us, bytes_per_launch, gbps); call after a sync."""
+        out = {}
+        for name, recs in self.pending.items():
+            ms = [a.elapsed_time(b) for a, b, _ in recs]
+            by = [n for _, _, n in recs]
+            tot = sum(ms)
+            out[name] = dict(launches=len(recs), total_ms=tot, avg_us=1e3 * tot / len(recs),
+                             bytes_per_launch=sum(by) / len(by),
+                             gbps=(sum(by) / 1e9) / (tot / 1e3) if tot > 0 else 0.0)
+        return out
+
+
+_timer = None
+
+
+def set_timer(timer):
+    """Install (or remove with None) an OpTimer; returns the previous one."""
+    global _timer
+    prev, _timer = _timer, timer
+    return prev
+
+
+def _run(name, nbytes, t, launch):
+    if _timer is None:
+        return launch()
+    return _timer.record(name, nbytes, t, launch)
+
+
 def register_backend(device_type, impl):
     """Install an op backend for a non-HIP device type (tests / cpu_baseline only)."""
     if device_type == "cuda":
@@ -75,9 +121,9 @@ class HipBackend:
         dist = torch.empty((B, P1, K), dtype=torch.float32, device=p1.device)
         idx = torch.empty((B, P1, K), dtype=torch.int64, device=p1.device)
         with _DeviceGuard(p1):
-            _lib.check(self.lib.tpg_knn_f32(_ptr(p1), _ptr(p2), _ptr(len1), _ptr(len2), B, P1, P2, D, K,
+            _lib.check(_run("knn", 4 * B * D * (P1 + P2) + 12 * B * P1 * K, p1, lambda: self.lib.tpg_knn_f32(_ptr(p1), _ptr(p2), _ptr(len1), _ptr(len2), B, P1, P2, D, K,
                                             -1.0 if r2 is None else r2, _ptr(dist), _ptr(idx),
-                                            _stream(p1)), "tpg_knn_f32")
+                                            _stream(p1))), "tpg_knn_f32")
         return dist, idx
 
     def chamfer_fwd(self, src, tgt):
@@ -88,8 +134,8 @@ class HipBackend:
         d2 = torch.empty((B, M), dtype=torch.float32, device=src.device)
         i2 = torch.empty((B, M), dtype=torch.int64, device=src.device)
         with _DeviceGuard(src):
-            _lib.check(self.lib.tpg_chamfer_fwd_f32(_ptr(src), _ptr(tgt), B, N, M, _ptr(d1), _ptr(i1),
-                                                    _ptr(d2), _ptr(i2), _stream(src)),
+            _lib.check(_run("chamfer_fwd", 24 * B * (N + M), src, lambda: self.lib.tpg_chamfer_fwd_f32(_ptr(src), _ptr(tgt), B, N, M, _ptr(d1), _ptr(i1),
+                                                    _ptr(d2), _ptr(i2), _stream(src))),
                        "tpg_chamfer_fwd_f32")
         return d1, i1, d2, i2
 
@@ -98,9 +144,9 @@ class HipBackend:
         M = tgt.shape[1]
         gs, gt = torch.empty_like(src), torch.empty_like(tgt)
         with _DeviceGuard(src):
-            _lib.check(self.lib.tpg_chamfer_bwd_f32(_ptr(src), _ptr(tgt), B, N, M, _ptr(i1), _ptr(i2),
+            _lib.check(_run("chamfer_bwd", 40 * B * (N + M), src, lambda: self.lib.tpg_chamfer_bwd_f32(_ptr(src), _ptr(tgt), B, N, M, _ptr(i1), _ptr(i2),
                                                     _ptr(g1), _ptr(g2), _ptr(gs), _ptr(gt),
-                                                    _stream(src)), "tpg_chamfer_bwd_f32")
+                                                    _stream(src))), "tpg_chamfer_bwd_f32")
         return gs, gt
 
     def fps(self, xyz, m):
@@ -108,7 +154,7 @@ class HipBackend:
         idx = torch.empty((B, m), dtype=torch.int32, device=xyz.device)
         temp = torch.empty((B, N), dtype=torch.float32, device=xyz.device) if N > 16384 else None
         with _DeviceGuard(xyz):
-            _lib.check(self.lib.tpg_fps_f32(_ptr(xyz), B, N, m, _ptr(temp), _ptr(idx), _stream(xyz)),
+            _lib.check(_run("fps", 12 * B * N + 4 * B * m, xyz, lambda: self.lib.tpg_fps_f32(_ptr(xyz), B, N, m, _ptr(temp), _ptr(idx), _stream(xyz))),
                        "tpg_fps_f32")
         return idx
 
@@ -117,16 +163,16 @@ class HipBackend:
         S = idx.shape[1]
         out = torch.empty((B, Cc, S), dtype=torch.float32, device=feat.device)
         with _DeviceGuard(feat):
-            _lib.check(self.lib.tpg_gather_fwd_f32(_ptr(feat), _ptr(idx), B, Cc, N, S, _ptr(out),
-                                                   _stream(feat)), "tpg_gather_fwd_f32")
+            _lib.check(_run("gather_fwd", 4 * B * (Cc * N + S + Cc * S), feat, lambda: self.lib.tpg_gather_fwd_f32(_ptr(feat), _ptr(idx), B, Cc, N, S, _ptr(out),
+                                                   _stream(feat))), "tpg_gather_fwd_f32")
         return out
 
     def gather_bwd(self, gout, idx, N):
         B, Cc, S = gout.shape
         g = torch.empty((B, Cc, N), dtype=torch.float32, device=gout.device)
         with _DeviceGuard(gout):
-            _lib.check(self.lib.tpg_gather_bwd_f32(_ptr(gout), _ptr(idx), B, Cc, N, S, _ptr(g),
-                                                   _stream(gout)), "tpg_gather_bwd_f32")
+            _lib.check(_run("gather_bwd", 4 * B * (Cc * N + S + Cc * S), gout, lambda: self.lib.tpg_gather_bwd_f32(_ptr(gout), _ptr(idx), B, Cc, N, S, _ptr(g),
+                                                   _stream(gout))), "tpg_gather_bwd_f32")
         return g
 
     def ball_query(self, radius, nsample, xyz, new_xyz):
@@ -134,8 +180,8 @@ class HipBackend:
         S = new_xyz.shape[1]
         idx = torch.empty((B, S, nsample), dtype=torch.int32, device=xyz.device)
         with _DeviceGuard(xyz):
-            _lib.check(self.lib.tpg_ball_query_f32(_ptr(xyz), _ptr(new_xyz), B, N, S, float(radius),
-                                                   nsample, _ptr(idx), _stream(xyz)),
+            _lib.check(_run("ball_query", 12 * B * (N + S) + 4 * B * S * nsample, xyz, lambda: self.lib.tpg_ball_query_f32(_ptr(xyz), _ptr(new_xyz), B, N, S, float(radius),
+                                                   nsample, _ptr(idx), _stream(xyz))),
                        "tpg_ball_query_f32")
         return idx
 
@@ -144,16 +190,16 @@ class HipBackend:
         _, S, K = idx.shape
         out = torch.empty((B, Cc, S, K), dtype=torch.float32, device=feat.device)
         with _DeviceGuard(feat):
-            _lib.check(self.lib.tpg_group_fwd_f32(_ptr(feat), _ptr(idx), B, Cc, N, S, K, _ptr(out),
-                                                  _stream(feat)), "tpg_group_fwd_f32")
+            _lib.check(_run("group_fwd", 4 * B * (Cc * N + S * K + Cc * S * K), feat, lambda: self.lib.tpg_group_fwd_f32(_ptr(feat), _ptr(idx), B, Cc, N, S, K, _ptr(out),
+                                                  _stream(feat))), "tpg_group_fwd_f32")
         return out
 
     def group_bwd(self, gout, idx, N):
         B, Cc, S, K = gout.shape
         g = torch.empty((B, Cc, N), dtype=torch.float32, device=gout.device)
         with _DeviceGuard(gout):
-            _lib.check(self.lib.tpg_group_bwd_f32(_ptr(gout), _ptr(idx), B, Cc, N, S, K, _ptr(g),
-                                                  _stream(gout)), "tpg_group_bwd_f32")
+            _lib.check(_run("group_bwd", 4 * B * (Cc * N + S * K + Cc * S * K), gout, lambda: self.lib.tpg_group_bwd_f32(_ptr(gout), _ptr(idx), B, Cc, N, S, K, _ptr(g),
+                                                  _stream(gout))), "tpg_group_bwd_f32")
         return g
 
     def three_nn(self, unknown, known):
