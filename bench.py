@@ -37,6 +37,14 @@ from tpgan_amd.set_abstraction import FluidSpatialDis, FluidTempoDis  # noqa: E4
 from tpgan_amd.srnet import SRNet  # noqa: E402
 from tpgan_amd.synthetic import fluid_clip, force_all_keep  # noqa: E402
 
+T_START = time.perf_counter()
+
+
+def log(msg):
+    """Progress on stderr (the JSON line on stdout stays alone)."""
+    print(f"[bench +{time.perf_counter() - T_START:7.1f}s] {msg}", file=sys.stderr, flush=True)
+
+
 HBM_PEAK_GBPS = 8000.0   # MI355X spec, /opt/skills/guides/MI355X_MICROARCH.md
 OPT = Namespace(use_vel=False, in_node_feats=3, cutoff=0.025, R=0.10, w=0.5)
 
@@ -116,7 +124,12 @@ def main():
     ap.add_argument("--dtype", choices=["bf16", "fp32"], default="bf16")
     ap.add_argument("--no-extra", action="store_true", help="skip roofline and cpu_baseline legs")
     ap.add_argument("--cpu-sample-batch", type=int, default=4)
+    ap.add_argument("--miopen", action="store_true",
+                    help="let PyTorch use MIOpen for conv/BN (first use JIT-compiles per shape: minutes)")
     args = ap.parse_args()
+    # 1x1 convs and BatchNorm go through rocBLAS / native kernels; MIOpen would JIT-compile one
+    # kernel per new shape on a fresh box, which swamps any short run.
+    torch.backends.cudnn.enabled = bool(args.miopen)
 
     rank, world, local = ddp.init_from_env()
     if world != args.gpus:
@@ -134,7 +147,11 @@ def main():
     clips = [fluid_clip(args.batch, args.points, 8, 3, seed=1234 + rank * 1000 + s, device=device)
              for s in range(4)]
 
-    run_steps(models, clips, args.warmup, sync, amp_dtype)
+    log(f"rank {rank}: models and clips resident, warming up")
+    for w in range(args.warmup):
+        run_steps(models, clips, 1, sync, amp_dtype, start=w)
+        torch.cuda.synchronize()
+        log(f"warm-up step {w + 1}/{args.warmup} done")
     ddp.barrier()
     torch.cuda.synchronize()
     t0 = time.perf_counter()
@@ -145,6 +162,7 @@ def main():
     if world > 1:
         torch.distributed.all_reduce(dt, op=torch.distributed.ReduceOp.MAX)
     dt = float(dt.item())
+    log(f"timed region: {args.steps} steps in {dt:.3f} s")
 
     line = {
         "metric": "GAN train-steps/sec (G+D) on 4096-pt x3-frame clips",
@@ -165,6 +183,7 @@ def main():
         roof, table = roofline_leg(models, clips, min(args.steps, 5), sync, amp_dtype)
         line["roofline"] = roof
         line["kernels"] = table
+        log("roofline leg done, timing the CPU baseline")
         line["cpu_baseline"] = cpu_baseline(args.cpu_sample_batch, args.batch, args.points)
     if rank == 0:
         print(json.dumps(line), flush=True)

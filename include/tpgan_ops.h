@@ -101,6 +101,36 @@ int tpg_three_interp_bwd_f32(const float *gout, const int32_t *idx, const float 
                              int B, int C, int m, int n, float *gfeat,
                              void *stream);
 
+/* ---- channels-last "row combine": gather the OUTPUT rows of the first MLP layer ----------
+ * A 1x1 convolution commutes with a gather, so the first layer of every grouped MLP on the
+ * path (EdgeConv: gcn_lib/pointnet/gcn.py:207-210; set abstraction: QueryAndGroup + mlps[0],
+ * discriminator.py:141-145; FlowEmbedding: discriminator.py:270-280) is applied to the N
+ * un-grouped points and its rows are gathered:
+ *   mode 0 GATHER: out[b,s,k,:] = U[b,idx[b,s,k],:]
+ *   mode 1 SUB   : out[b,s,k,:] = U[b,idx[b,s,k],:] - QE[b,s,:]
+ *   mode 2 EDGE  : out[b,s,k,:] = U[b,idx,:] + lrelu(QE[b,idx,:] - QE[b,s,:], slope)  (S == N)
+ * U (B,N,C), QE (B,S,C) of dtype_in; idx (B,S,K) int32; out (B,S,K,C) of dtype_out.  Rows
+ * are channels-last; C % 4 == 0 when both types are f32, else C % 8 == 0; 16-B aligned bases.
+ * Arithmetic is fp32 in registers with one rounding on store (f32 in -> bf16 out keeps the
+ * difference U - QE exact before the single bf16 rounding). */
+typedef enum { TPG_DTYPE_F32 = 0, TPG_DTYPE_BF16 = 1 } tpg_dtype;
+
+int tpg_rowcombine_fwd(const void *U, const void *QE, const int32_t *idx, int mode, int dtype_in,
+                       int dtype_out, int B, int N, int S, int K, int C, float slope, void *out,
+                       void *stream);
+
+/* per-cloud inverted index of idx (B,SK) with values in [0,N): offs (B,N+1), list (B,SK)
+ * = flat (s,k) entry ids grouped by destination row (order inside a group unspecified). */
+int tpg_invert_index(const int32_t *idx, int B, int N, int SK, int32_t *offs, int32_t *list,
+                     void *stream);
+
+/* backward of tpg_rowcombine_fwd; atomics-free gather-reduce over the inverted index.
+ * gout (B,S,K,C) of dtype_out; gU (B,N,C) and gQE (grad of QE: (B,S,C) for SUB and EDGE,
+ * ignored for GATHER) of dtype_in.  E = the forward's QE (EDGE only, else NULL). */
+int tpg_rowcombine_bwd(const void *gout, const int32_t *idx, const int32_t *offs, const int32_t *list,
+                       const void *E, int mode, int dtype_in, int dtype_out, int B, int N, int S, int K,
+                       int C, float slope, void *gU, void *gQE, void *stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -166,3 +166,26 @@ def three_interp_bwd(gout, idx, w, m):
     _chk(lib().tpgref_three_interp_bwd_f32(_f(gout), _i32(idx), _f(w), B, Cc, m, n, _f(g)),
          "three_interp_bwd")
     return g
+
+
+def rowcombine_fwd(U, QE, idx, mode, slope=0.2):
+    U, idx = _c(U, np.float32), _c(idx, np.int32)
+    QE = None if QE is None else _c(QE, np.float32)
+    B, N, Cc = U.shape
+    _, S, K = idx.shape
+    out = np.empty((B, S, K, Cc), np.float32)
+    _chk(lib().tpgref_rowcombine_fwd_f32(_f(U), None if QE is None else _f(QE), _i32(idx), mode, B, N, S,
+                                         K, Cc, C.c_float(slope), _f(out)), "rowcombine_fwd")
+    return out
+
+
+def rowcombine_bwd(gout, idx, E, mode, N, slope=0.2):
+    gout, idx = _c(gout, np.float32), _c(idx, np.int32)
+    E = None if E is None else _c(E, np.float32)
+    B, S, K, Cc = gout.shape
+    gU = np.empty((B, N, Cc), np.float32)
+    gQE = np.empty((B, S, Cc), np.float32) if mode != 0 else None
+    _chk(lib().tpgref_rowcombine_bwd_f32(_f(gout), _i32(idx), None if E is None else _f(E), mode, B, N, S, K,
+                                         Cc, C.c_float(slope), _f(gU), None if gQE is None else _f(gQE)),
+         "rowcombine_bwd")
+    return gU, gQE

@@ -73,6 +73,17 @@ class OracleBackend:
         return _t(R.three_interp_bwd(_np(gout), _np(idx), _np(w), m))
 
 
+    # ---- row combine (fp32 on the CPU path) ----------------------------------------------
+    def rowcombine_fwd(self, U, QE, idx, mode, slope, out_dtype):
+        out = R.rowcombine_fwd(_np(U.float()), None if QE is None else _np(QE.float()), _np(idx), mode, slope)
+        return _t(out).to(out_dtype)
+
+    def rowcombine_bwd(self, gout, idx, E, mode, N, slope, in_dtype):
+        gU, gQE = R.rowcombine_bwd(_np(gout.float()), _np(idx), None if E is None else _np(E.float()), mode,
+                                   N, slope)
+        return _t(gU).to(in_dtype), (None if gQE is None else _t(gQE).to(in_dtype))
+
+
 def install():
     import tpgan_amd.ops as ops
     ops.register_backend("cpu", OracleBackend())

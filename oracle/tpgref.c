@@ -335,3 +335,64 @@ int tpgref_three_interp_bwd_f32(const float *gout, const int32_t *idx,
         }
     return TPG_OK;
 }
+
+/* ------------------------------------------------------------------------ */
+/* Row combine (channels-last) -- restates the build's OWN fused form of      */
+/* "group -> first 1x1 conv" (include/tpgan_ops.h, tpg_rowcombine_*).  The    */
+/* reference computes conv(group(x)) (gcn_lib/pointnet/gcn.py:207-210,        */
+/* discriminator.py:141-145,270-280); equality of the two forms up to fp32    */
+/* rounding is pinned at model level by tests/golden/.  fp32 only; bf16 is     */
+/* emulated in the tests by rounding inputs/outputs.                           */
+/* ------------------------------------------------------------------------ */
+static inline float lrelu(float d, float slope) { return d > 0.0f ? d : d * slope; }
+
+int tpgref_rowcombine_fwd_f32(const float *U, const float *QE, const int32_t *idx, int mode, int B,
+                              int N, int S, int K, int C, float slope, float *out) {
+    if (B < 0 || N <= 0 || S < 0 || K < 0 || C <= 0 || mode < 0 || mode > 2) return TPG_ERR_ARG;
+    if (mode == 2 && S != N) return TPG_ERR_ARG;
+#pragma omp parallel for collapse(2) schedule(static)
+    for (int b = 0; b < B; ++b)
+        for (int s = 0; s < S; ++s)
+            for (int k = 0; k < K; ++k) {
+                const size_t row = ((size_t)b * S + s) * K + k;
+                const int n = idx[row];
+                const float *u = U + ((size_t)b * N + n) * C;
+                float *o = out + row * C;
+                for (int c = 0; c < C; ++c) {
+                    if (mode == 0) o[c] = u[c];
+                    else if (mode == 1) o[c] = u[c] - QE[((size_t)b * S + s) * C + c];
+                    else {
+                        const float d = QE[((size_t)b * N + n) * C + c] - QE[((size_t)b * S + s) * C + c];
+                        o[c] = u[c] + lrelu(d, slope);
+                    }
+                }
+            }
+    return TPG_OK;
+}
+
+/* sums run in (s,k) order per destination (the HIP order is unspecified -> 1e-5) */
+int tpgref_rowcombine_bwd_f32(const float *gout, const int32_t *idx, const float *E, int mode, int B,
+                              int N, int S, int K, int C, float slope, float *gU, float *gQE) {
+    if (B < 0 || N <= 0 || S < 0 || K < 0 || C <= 0 || mode < 0 || mode > 2) return TPG_ERR_ARG;
+    memset(gU, 0, sizeof(float) * (size_t)B * N * C);
+    if (mode != 0) memset(gQE, 0, sizeof(float) * (size_t)B * S * C);
+#pragma omp parallel for schedule(static)
+    for (int b = 0; b < B; ++b)
+        for (int s = 0; s < S; ++s)
+            for (int k = 0; k < K; ++k) {
+                const size_t row = ((size_t)b * S + s) * K + k;
+                const int n = idx[row];
+                const float *g = gout + row * C;
+                for (int c = 0; c < C; ++c) {
+                    gU[((size_t)b * N + n) * C + c] += g[c];
+                    if (mode == 1) gQE[((size_t)b * S + s) * C + c] -= g[c];
+                    if (mode == 2) {
+                        const float d = E[((size_t)b * N + n) * C + c] - E[((size_t)b * S + s) * C + c];
+                        const float ge = d > 0.0f ? g[c] : g[c] * slope;
+                        gQE[((size_t)b * N + n) * C + c] += ge;
+                        gQE[((size_t)b * S + s) * C + c] -= ge;
+                    }
+                }
+            }
+    return TPG_OK;
+}

@@ -1,0 +1,351 @@
+// Row-gather "combine" kernels: the MI355X form of group -> first MLP layer.
+//
+// The reference gathers neighbour features into a (B,C,S,K) tensor and THEN applies the
+// first 1x1 convolution to every one of the S*K grouped positions
+// (gcn_lib/pointnet/gcn.py:207-210; QueryAndGroup + mlps[0] at discriminator.py:141-145;
+// discriminator.py:270-280).  A 1x1 convolution commutes with a gather, so this build
+// applies the first layer to the N un-grouped points (K..32x fewer FLOPs) and gathers its
+// OUTPUT rows.  With channels-last rows (B,N,C) a gathered neighbour is one contiguous row
+// of C*sizeof(T) bytes, so reads and writes are fully coalesced 16-byte vectors:
+//
+//   mode GATHER : out[b,s,k,:] = U[b,idx[b,s,k],:]
+//   mode SUB    : out[b,s,k,:] = U[b,idx[b,s,k],:] - Q[b,s,:]           (set abstraction,
+//                 flow embedding: Q carries the centre-dependent terms)
+//   mode EDGE   : out[b,s,k,:] = A[b,idx,:] + lrelu(E[b,idx,:] - E[b,s,:])  (EdgeConv: A =
+//                 lrelu(Wn f), E = We f; requires S == N)
+//
+// Backward is atomics-free: a per-cloud inverted index (destination row -> list of (s,k)
+// entries, built by one counting sort in LDS) turns the scatter-add into a gather-reduce
+// where each destination row is summed by one group of lanes and written exactly once.
+// Element types: fp32 and bf16 (bf16 halves the bytes of the largest tensors; arithmetic is
+// fp32 in registers, one rounding on store).
+#include <hip/hip_bf16.h>
+
+#include "tpg_common.hpp"
+
+namespace {
+
+enum { MODE_GATHER = 0, MODE_SUB = 1, MODE_EDGE = 2 };
+
+// NE consecutive elements of T <-> NE floats (16-byte vector accesses).
+template <typename T, int NE> struct RowIO;
+template <int NE> struct RowIO<float, NE> {
+    static __device__ __forceinline__ void load(const float *p, float (&v)[NE]) {
+#pragma unroll
+        for (int i = 0; i < NE / 4; ++i) {
+            const float4 x = reinterpret_cast<const float4 *>(p)[i];
+            v[4 * i] = x.x; v[4 * i + 1] = x.y; v[4 * i + 2] = x.z; v[4 * i + 3] = x.w;
+        }
+    }
+    static __device__ __forceinline__ void store(float *p, const float (&v)[NE]) {
+#pragma unroll
+        for (int i = 0; i < NE / 4; ++i)
+            reinterpret_cast<float4 *>(p)[i] = make_float4(v[4 * i], v[4 * i + 1], v[4 * i + 2], v[4 * i + 3]);
+    }
+};
+template <> struct RowIO<__hip_bfloat16, 8> {
+    static __device__ __forceinline__ void load(const __hip_bfloat16 *p, float (&v)[8]) {
+        const uint4 x = *reinterpret_cast<const uint4 *>(p);
+        const unsigned w[4] = {x.x, x.y, x.z, x.w};
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            v[2 * i] = __uint_as_float(w[i] << 16);
+            v[2 * i + 1] = __uint_as_float(w[i] & 0xffff0000u);
+        }
+    }
+    static __device__ __forceinline__ void store(__hip_bfloat16 *p, const float (&v)[8]) {
+        unsigned w[4];
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const __hip_bfloat16 lo = __float2bfloat16(v[2 * i]);       // round-to-nearest-even
+            const __hip_bfloat16 hi = __float2bfloat16(v[2 * i + 1]);
+            w[i] = (unsigned)(*reinterpret_cast<const unsigned short *>(&lo)) |
+                   ((unsigned)(*reinterpret_cast<const unsigned short *>(&hi)) << 16);
+        }
+        *reinterpret_cast<uint4 *>(p) = make_uint4(w[0], w[1], w[2], w[3]);
+    }
+};
+// elements per thread: 8 as soon as one side is bf16 (16-byte bf16 vectors), else 4
+template <typename TA, typename TB> struct Elems {
+    static constexpr int NE = (sizeof(TA) == 2 || sizeof(TB) == 2) ? 8 : 4;
+};
+
+// ------------------------------------------------------------------ forward
+template <typename TI, typename TO, int MODE>
+__global__ __launch_bounds__(256) void rowcombine_fwd_kernel(
+    const TI *__restrict__ U, const TI *__restrict__ QE, const int32_t *__restrict__ idx, int N, int S,
+    int K, int C, float slope, TO *__restrict__ out, unsigned total) {
+    constexpr int NE = Elems<TI, TO>::NE;
+    using In = RowIO<TI, NE>;
+    using Out = RowIO<TO, NE>;
+    const unsigned cpr = (unsigned)C / NE;  // 16-byte chunks per row
+    for (unsigned t = blockIdx.x * 256u + threadIdx.x; t < total; t += gridDim.x * 256u) {
+        const unsigned row = t / cpr;            // flat (b,s,k)
+        const unsigned col = (t - row * cpr) * NE;
+        const unsigned bs = row / (unsigned)K;   // flat (b,s)
+        const unsigned b = bs / (unsigned)S;
+        const int n = tpg_clamp_idx(idx[row], N);
+        float u[NE];
+        In::load(U + ((size_t)b * N + n) * C + col, u);
+        if (MODE == MODE_SUB) {
+            float q[NE];
+            In::load(QE + (size_t)bs * C + col, q);
+#pragma unroll
+            for (int i = 0; i < NE; ++i) u[i] = u[i] - q[i];
+        } else if (MODE == MODE_EDGE) {
+            float en[NE], es[NE];
+            In::load(QE + ((size_t)b * N + n) * C + col, en);
+            In::load(QE + (size_t)bs * C + col, es);   // S == N: centre row of E
+#pragma unroll
+            for (int i = 0; i < NE; ++i) {
+                const float d = en[i] - es[i];
+                u[i] = u[i] + (d > 0.0f ? d : d * slope);
+            }
+        }
+        Out::store(out + (size_t)row * C + col, u);
+    }
+}
+
+// ------------------------------------------------------------------ inverted index
+// One workgroup per cloud: histogram of destinations in LDS, exclusive scan, fill.
+// offs (B,N+1), list (B,S*K) holds flat (s,k) entry ids grouped by destination.
+__global__ __launch_bounds__(1024) void invert_index_kernel(const int32_t *__restrict__ idx, int N,
+                                                            int SK, int32_t *__restrict__ offs,
+                                                            int32_t *__restrict__ list) {
+    extern __shared__ __attribute__((aligned(16))) int inv_smem[];  // [N] counters + [32] scan slots
+    int *cnt = inv_smem;
+    int *wsum = inv_smem + N;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int b = blockIdx.x;
+    const int32_t *id = idx + (size_t)b * SK;
+    for (int n = tid; n < N; n += 1024) cnt[n] = 0;
+    __syncthreads();
+    for (int e = tid; e < SK; e += 1024) atomicAdd(&cnt[tpg_clamp_idx(id[e], N)], 1);
+    __syncthreads();
+    // exclusive scan of cnt[0..N): each thread owns a contiguous span
+    const int per = (N + 1023) / 1024;
+    const int lo = min(tid * per, N), hi = min(lo + per, N);
+    int local = 0;
+    for (int n = lo; n < hi; ++n) local += cnt[n];
+    int incl = local;
+#pragma unroll
+    for (int d = 1; d < 64; d <<= 1) {
+        const int o = __shfl_up(incl, d);
+        if (lane >= d) incl += o;
+    }
+    if (lane == 63) wsum[wave] = incl;
+    __syncthreads();
+    if (wave == 0) {
+        int w = lane < 16 ? wsum[lane] : 0;
+#pragma unroll
+        for (int d = 1; d < 16; d <<= 1) {
+            const int o = __shfl_up(w, d);
+            if (lane >= d) w += o;
+        }
+        if (lane < 16) wsum[16 + lane] = w;  // inclusive prefix of wave sums
+    }
+    __syncthreads();
+    int run = incl - local + (wave ? wsum[16 + wave - 1] : 0);  // exclusive prefix of this span
+    int32_t *of = offs + (size_t)b * (N + 1);
+    for (int n = lo; n < hi; ++n) {
+        const int c = cnt[n];
+        of[n] = run;
+        cnt[n] = run;  // becomes the fill cursor
+        run += c;
+    }
+    if (tid == 0) of[N] = SK;
+    __syncthreads();
+    int32_t *ls = list + (size_t)b * SK;
+    for (int e = tid; e < SK; e += 1024) {
+        const int pos = atomicAdd(&cnt[tpg_clamp_idx(id[e], N)], 1);
+        ls[pos] = e;
+    }
+}
+
+// ------------------------------------------------------------------ backward
+// one 16-byte chunk of one destination row per thread; gU (and gE for EDGE) written once.
+template <typename TI, typename TG, int MODE>
+__global__ __launch_bounds__(256) void rowcombine_bwd_kernel(
+    const TG *__restrict__ gout, const int32_t *__restrict__ idx, const int32_t *__restrict__ offs,
+    const int32_t *__restrict__ list, const TI *__restrict__ E, int N, int S, int K, int C, float slope,
+    TI *__restrict__ gU, TI *__restrict__ gE, unsigned total) {
+    constexpr int NE = Elems<TI, TG>::NE;
+    using In = RowIO<TI, NE>;
+    using Gr = RowIO<TG, NE>;
+    const unsigned cpr = (unsigned)C / NE;
+    const size_t SK = (size_t)S * K;
+    for (unsigned t = blockIdx.x * 256u + threadIdx.x; t < total; t += gridDim.x * 256u) {
+        const unsigned drow = t / cpr;  // flat (b,n)
+        const unsigned col = (t - drow * cpr) * NE;
+        const unsigned b = drow / (unsigned)N;
+        const unsigned n = drow - b * (unsigned)N;
+        const int32_t *of = offs + (size_t)b * (N + 1);
+        const int32_t *ls = list + (size_t)b * SK;
+        const TG *go = gout + (size_t)b * SK * C + col;
+        float acc[NE], accE[NE], en[NE];
+#pragma unroll
+        for (int i = 0; i < NE; ++i) { acc[i] = 0.0f; accE[i] = 0.0f; }
+        if (MODE == MODE_EDGE) In::load(E + (size_t)drow * C + col, en);
+        const int p1 = of[n + 1];
+        for (int p = of[n]; p < p1; ++p) {
+            const int e = ls[p];
+            float g[NE];
+            Gr::load(go + (size_t)e * C, g);
+#pragma unroll
+            for (int i = 0; i < NE; ++i) acc[i] += g[i];
+            if (MODE == MODE_EDGE) {
+                float es[NE];
+                In::load(E + ((size_t)b * N + (unsigned)e / (unsigned)K) * C + col, es);
+#pragma unroll
+                for (int i = 0; i < NE; ++i) accE[i] += (en[i] - es[i] > 0.0f) ? g[i] : g[i] * slope;
+            }
+        }
+        if (MODE == MODE_EDGE) {
+            // this row as a CENTRE: -sum_k g * lrelu'(E[nbr] - E[n])   (S == N)
+            for (int k = 0; k < K; ++k) {
+                const size_t e = (size_t)n * K + k;
+                const int nb = tpg_clamp_idx(idx[(size_t)b * SK + e], N);
+                float g[NE], eb[NE];
+                Gr::load(go + e * C, g);
+                In::load(E + ((size_t)b * N + nb) * C + col, eb);
+#pragma unroll
+                for (int i = 0; i < NE; ++i) accE[i] -= (eb[i] - en[i] > 0.0f) ? g[i] : g[i] * slope;
+            }
+            In::store(gE + (size_t)drow * C + col, accE);
+        }
+        In::store(gU + (size_t)drow * C + col, acc);
+    }
+}
+
+// gQ[b,s,:] = -sum_k gout[b,s,k,:]
+template <typename TI, typename TG>
+__global__ __launch_bounds__(256) void rowsum_neg_kernel(const TG *__restrict__ gout, int K, int C,
+                                                         TI *__restrict__ gQ, unsigned total) {
+    constexpr int NE = Elems<TI, TG>::NE;
+    const unsigned cpr = (unsigned)C / NE;
+    for (unsigned t = blockIdx.x * 256u + threadIdx.x; t < total; t += gridDim.x * 256u) {
+        const unsigned bs = t / cpr;
+        const unsigned col = (t - bs * cpr) * NE;
+        float acc[NE];
+#pragma unroll
+        for (int i = 0; i < NE; ++i) acc[i] = 0.0f;
+        for (int k = 0; k < K; ++k) {
+            float g[NE];
+            RowIO<TG, NE>::load(gout + ((size_t)bs * K + k) * C + col, g);
+#pragma unroll
+            for (int i = 0; i < NE; ++i) acc[i] -= g[i];
+        }
+        RowIO<TI, NE>::store(gQ + (size_t)bs * C + col, acc);
+    }
+}
+
+unsigned grid_for(unsigned total) {
+    const unsigned blocks = (total + 255u) / 256u;
+    return blocks < 1u ? 1u : (blocks > 16384u ? 16384u : blocks);  // 64 workgroups per CU, then stride
+}
+
+bool aligned16(const void *a, const void *b, const void *c, const void *d) {
+    return ((reinterpret_cast<uintptr_t>(a) | reinterpret_cast<uintptr_t>(b) | reinterpret_cast<uintptr_t>(c) |
+             reinterpret_cast<uintptr_t>(d)) & 15) == 0;
+}
+bool dtype_ok(int d) { return d == TPG_DTYPE_F32 || d == TPG_DTYPE_BF16; }
+
+template <typename TI, typename TO>
+int fwd_go(const void *U, const void *QE, const int32_t *idx, int mode, int B, int N, int S, int K,
+           int C, float slope, void *out, hipStream_t st) {
+    constexpr int NE = Elems<TI, TO>::NE;
+    if (C % NE) return TPG_ERR_UNSUPPORTED;
+    const unsigned long long total64 = (unsigned long long)B * S * K * (C / NE);
+    if (total64 >= 0x7fffffffULL) return TPG_ERR_ARG;
+    const unsigned total = (unsigned)total64;
+    const dim3 g(grid_for(total)), blk(256);
+    const TI *u = static_cast<const TI *>(U), *q = static_cast<const TI *>(QE);
+    TO *o = static_cast<TO *>(out);
+    if (mode == MODE_GATHER)
+        hipLaunchKernelGGL((rowcombine_fwd_kernel<TI, TO, MODE_GATHER>), g, blk, 0, st, u, q, idx, N, S, K, C, slope, o, total);
+    else if (mode == MODE_SUB)
+        hipLaunchKernelGGL((rowcombine_fwd_kernel<TI, TO, MODE_SUB>), g, blk, 0, st, u, q, idx, N, S, K, C, slope, o, total);
+    else
+        hipLaunchKernelGGL((rowcombine_fwd_kernel<TI, TO, MODE_EDGE>), g, blk, 0, st, u, q, idx, N, S, K, C, slope, o, total);
+    return TPG_OK;
+}
+
+template <typename TI, typename TG>
+int bwd_go(const void *gout, const int32_t *idx, const int32_t *offs, const int32_t *list, const void *E,
+           int mode, int B, int N, int S, int K, int C, float slope, void *gU, void *gQE, hipStream_t st) {
+    constexpr int NE = Elems<TI, TG>::NE;
+    if (C % NE) return TPG_ERR_UNSUPPORTED;
+    const unsigned long long total64 = (unsigned long long)B * N * (C / NE);
+    const unsigned long long totq64 = (unsigned long long)B * S * (C / NE);
+    if (total64 >= 0x7fffffffULL || totq64 >= 0x7fffffffULL) return TPG_ERR_ARG;
+    const unsigned total = (unsigned)total64;
+    const dim3 g(grid_for(total)), blk(256);
+    const TG *go = static_cast<const TG *>(gout);
+    const TI *e = static_cast<const TI *>(E);
+    TI *gu = static_cast<TI *>(gU), *gq = static_cast<TI *>(gQE);
+    if (mode == MODE_EDGE) {
+        hipLaunchKernelGGL((rowcombine_bwd_kernel<TI, TG, MODE_EDGE>), g, blk, 0, st, go, idx, offs, list, e, N, S, K, C, slope, gu, gq, total);
+    } else {
+        hipLaunchKernelGGL((rowcombine_bwd_kernel<TI, TG, MODE_GATHER>), g, blk, 0, st, go, idx, offs, list, e, N, S, K, C, slope, gu, gq, total);
+        if (mode == MODE_SUB) {
+            const unsigned totq = (unsigned)totq64;
+            hipLaunchKernelGGL((rowsum_neg_kernel<TI, TG>), dim3(grid_for(totq)), blk, 0, st, go, K, C, gq, totq);
+        }
+    }
+    return TPG_OK;
+}
+
+#define TPG_DISPATCH2(din, dout, CALL)                                                   \
+    ((din) == TPG_DTYPE_F32 ? ((dout) == TPG_DTYPE_F32 ? CALL(float, float) : CALL(float, __hip_bfloat16)) \
+                            : ((dout) == TPG_DTYPE_F32 ? CALL(__hip_bfloat16, float)                    \
+                                                       : CALL(__hip_bfloat16, __hip_bfloat16)))
+
+}  // namespace
+
+extern "C" int tpg_rowcombine_fwd(const void *U, const void *QE, const int32_t *idx, int mode, int dtype_in,
+                                  int dtype_out, int B, int N, int S, int K, int C, float slope, void *out,
+                                  void *stream) {
+    if (B < 0 || N <= 0 || S < 0 || K < 0 || C <= 0 || mode < 0 || mode > 2) return TPG_ERR_ARG;
+    if ((long long)B * S * K == 0) return TPG_OK;
+    if (!U || !idx || !out || (mode != MODE_GATHER && !QE)) return TPG_ERR_ARG;
+    if (mode == MODE_EDGE && S != N) return TPG_ERR_ARG;
+    if (!dtype_ok(dtype_in) || !dtype_ok(dtype_out) || !aligned16(U, QE, out, nullptr)) return TPG_ERR_UNSUPPORTED;
+    hipStream_t st = tpg_stream(stream);
+#define TPG_FWD(TI, TO) fwd_go<TI, TO>(U, QE, idx, mode, B, N, S, K, C, slope, out, st)
+    const int rc = TPG_DISPATCH2(dtype_in, dtype_out, TPG_FWD);
+#undef TPG_FWD
+    if (rc) return rc;
+    TPG_RETURN_IF_LAUNCH_FAILED();
+    return TPG_OK;
+}
+
+extern "C" int tpg_invert_index(const int32_t *idx, int B, int N, int SK, int32_t *offs, int32_t *list,
+                                void *stream) {
+    if (B < 0 || N <= 0 || SK < 0) return TPG_ERR_ARG;
+    if (B == 0) return TPG_OK;
+    if (!idx || !offs || !list) return TPG_ERR_ARG;
+    const size_t smem = sizeof(int) * ((size_t)N + 32);
+    if (smem > 64 * 1024) return TPG_ERR_UNSUPPORTED;   // N <= 16352 destination rows per cloud
+    hipLaunchKernelGGL(invert_index_kernel, dim3(B), dim3(1024), smem, tpg_stream(stream), idx, N, SK, offs, list);
+    TPG_RETURN_IF_LAUNCH_FAILED();
+    return TPG_OK;
+}
+
+extern "C" int tpg_rowcombine_bwd(const void *gout, const int32_t *idx, const int32_t *offs,
+                                  const int32_t *list, const void *E, int mode, int dtype_in, int dtype_out,
+                                  int B, int N, int S, int K, int C, float slope, void *gU, void *gQE,
+                                  void *stream) {
+    if (B < 0 || N <= 0 || S < 0 || K < 0 || C <= 0 || mode < 0 || mode > 2) return TPG_ERR_ARG;
+    if (B == 0) return TPG_OK;
+    if (!gout || !idx || !offs || !list || !gU) return TPG_ERR_ARG;
+    if (mode == MODE_EDGE && (S != N || !E || !gQE)) return TPG_ERR_ARG;
+    if (mode == MODE_SUB && !gQE) return TPG_ERR_ARG;
+    if (!dtype_ok(dtype_in) || !dtype_ok(dtype_out) || !aligned16(gout, gU, gQE, E)) return TPG_ERR_UNSUPPORTED;
+    hipStream_t st = tpg_stream(stream);
+#define TPG_BWD(TI, TG) bwd_go<TI, TG>(gout, idx, offs, list, E, mode, B, N, S, K, C, slope, gU, gQE, st)
+    const int rc = TPG_DISPATCH2(dtype_in, dtype_out, TPG_BWD);
+#undef TPG_BWD
+    if (rc) return rc;
+    TPG_RETURN_IF_LAUNCH_FAILED();
+    return TPG_OK;
+}

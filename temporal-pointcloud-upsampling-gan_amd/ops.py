@@ -232,6 +232,45 @@ class HipBackend:
         return g
 
 
+    # ---- channels-last row combine (csrc/rowgather.hip) --------------------------------
+    def rowcombine_fwd(self, U, QE, idx, mode, slope, out_dtype):
+        B, N, Cc = U.shape
+        _, S, K = idx.shape
+        out = torch.empty((B, S, K, Cc), dtype=out_dtype, device=U.device)
+        nbytes = U.element_size() * B * Cc * (N + (S if QE is not None else 0)) + 4 * B * S * K \
+            + out.element_size() * B * S * K * Cc
+        with _DeviceGuard(U):
+            _lib.check(_run("rowcombine_fwd", nbytes, U, lambda: self.lib.tpg_rowcombine_fwd(
+                _ptr(U), _ptr(QE), _ptr(idx), mode, _DTYPE_CODE[U.dtype], _DTYPE_CODE[out_dtype], B, N, S, K,
+                Cc, float(slope), _ptr(out), _stream(U))), "tpg_rowcombine_fwd")
+        return out
+
+    def invert_index(self, idx, N):
+        B = idx.shape[0]
+        SK = idx[0].numel()
+        offs = torch.empty((B, N + 1), dtype=torch.int32, device=idx.device)
+        lst = torch.empty((B, SK), dtype=torch.int32, device=idx.device)
+        with _DeviceGuard(idx):
+            _lib.check(_run("invert_index", 4 * B * (2 * SK + N + 1), idx, lambda: self.lib.tpg_invert_index(
+                _ptr(idx), B, N, SK, _ptr(offs), _ptr(lst), _stream(idx))), "tpg_invert_index")
+        return offs, lst
+
+    def rowcombine_bwd(self, gout, idx, E, mode, N, slope, in_dtype):
+        B, S, K, Cc = gout.shape
+        offs, lst = self.invert_index(idx, N)
+        gU = torch.empty((B, N, Cc), dtype=in_dtype, device=gout.device)
+        gQE = torch.empty((B, S, Cc), dtype=in_dtype, device=gout.device) if mode != 0 else None
+        nbytes = gout.element_size() * B * S * K * Cc * (2 if mode == 1 else 1) + 8 * B * S * K \
+            + gU.element_size() * B * Cc * (N + (S if mode else 0))
+        with _DeviceGuard(gout):
+            _lib.check(_run("rowcombine_bwd", nbytes, gout, lambda: self.lib.tpg_rowcombine_bwd(
+                _ptr(gout), _ptr(idx), _ptr(offs), _ptr(lst), _ptr(E), mode, _DTYPE_CODE[in_dtype],
+                _DTYPE_CODE[gout.dtype], B, N, S, K, Cc, float(slope), _ptr(gU), _ptr(gQE),
+                _stream(gout))), "tpg_rowcombine_bwd")
+        return gU, gQE
+
+
+_DTYPE_CODE = {torch.float32: 0, torch.bfloat16: 1}
 _hip = None
 
 
@@ -452,3 +491,51 @@ def chamfer_nn(src, tgt):
     _need(src.shape[0] == tgt.shape[0], "batch mismatch")
     _same_device(src, tgt)
     return _ChamferNN.apply(src.float().contiguous(), tgt.float().contiguous())
+
+
+# ------------------------------------------------------- channels-last row combine
+ROW_GATHER, ROW_SUB, ROW_EDGE = 0, 1, 2
+
+
+class _RowCombine(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, U, QE, idx, mode, slope, out_dtype):
+        be = backend_for(U)
+        out = be.rowcombine_fwd(U, QE, idx, mode, slope, out_dtype)
+        ctx.save_for_backward(idx, QE if mode == ROW_EDGE else None)
+        ctx.mode, ctx.slope, ctx.N, ctx.in_dtype = mode, slope, U.shape[1], U.dtype
+        ctx.has_q = QE is not None
+        return out
+
+    @staticmethod
+    def backward(ctx, gout):
+        idx, E = ctx.saved_tensors
+        gout = gout.contiguous()
+        if gout.dtype not in _DTYPE_CODE:
+            gout = gout.float()
+        gU, gQE = backend_for(gout).rowcombine_bwd(gout, idx, E, ctx.mode, ctx.N, ctx.slope, ctx.in_dtype)
+        return gU, (gQE if ctx.has_q else None), None, None, None, None
+
+
+def row_combine(U, QE, idx, mode, slope=0.2, out_dtype=None):
+    """Channels-last gather of first-layer rows (include/tpgan_ops.h, tpg_rowcombine_fwd).
+
+    U (B,N,C); QE (B,S,C) or None; idx (B,S,K) int32 -> (B,S,K,C).
+      ROW_GATHER: U[idx]      ROW_SUB: U[idx] - QE[s]      ROW_EDGE: U[idx] + lrelu(QE[idx] - QE[s])
+    U/QE fp32 or bf16; out_dtype defaults to U.dtype (fp32 in -> bf16 out is supported)."""
+    _need(U.dim() == 3 and idx.dim() == 3 and idx.dtype == torch.int32, "U (B,N,C), idx (B,S,K) int32")
+    _need(U.dtype in _DTYPE_CODE, f"row_combine supports fp32/bf16, got {U.dtype}")
+    _need(U.shape[0] == idx.shape[0], "batch mismatch")
+    out_dtype = out_dtype or U.dtype
+    U = U.contiguous()
+    idx = idx.contiguous()
+    if mode == ROW_GATHER:
+        QE = None
+    else:
+        _need(QE is not None and QE.shape == (U.shape[0], idx.shape[1], U.shape[2]), "QE must be (B,S,C)")
+        QE = QE.to(U.dtype).contiguous()
+        if mode == ROW_EDGE:
+            _need(idx.shape[1] == U.shape[1], "EDGE mode needs S == N")
+    ne = 4 if (U.dtype == torch.float32 and out_dtype == torch.float32) else 8
+    _need(U.shape[2] % ne == 0, f"channel count {U.shape[2]} must be a multiple of {ne}")
+    return _RowCombine.apply(U, QE, idx, mode, float(slope), out_dtype)

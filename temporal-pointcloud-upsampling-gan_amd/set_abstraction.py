@@ -4,8 +4,20 @@ Host-side mirror of the reference's `discriminator.py` (knn :13-21, ball_query_w
 :24-40, index_points :43-60, build_shared_mlp :63-78, _PointnetSAModuleBase :83-153,
 MSGSetConv :156-200, SSGSetConv :203-232, FlowEmbedding :235-283, FlowModule :286-322,
 ActionTempoDis :325-402, ActionSpatialDis :405-470, FluidTempoDis :473-559,
-FluidSpatialDis :562-629) with identical parameter / buffer names.  FPS, ball query,
-grouping, gather and the neighbour searches run on the HIP kernels.
+FluidSpatialDis :562-629) with identical parameter / buffer names.  FPS, ball query and the
+neighbour searches run on the HIP kernels.
+
+Inner loop, MI355X-first (same results up to fp32 rounding, pinned by tests/golden):
+the reference builds cat([group(xyz) - centre, group(feat)]) of shape (B,3+C,S,ns) and runs
+the first spectral-norm conv on all S*ns grouped positions.  Here the first conv (same
+weight, same single power iteration per call) is applied to the N un-grouped rows
+[xyz | feat] and to the S centres, and the rows of its output are gathered:
+
+    y1[b,s,j,:] = U[b, idx[b,s,j], :] - Q[b,s,:]      U = W1 [xyz|feat],  Q = W1[:, :3] centre
+
+(ops.row_combine, one coalesced row-copy kernel; ns-fold fewer first-layer FLOPs, no
+(B,3+C,S,ns) tensor).  The remaining layers are GEMMs on channels-last rows with
+BatchNorm over the (B*S*ns) row axis -- the same statistics as BatchNorm2d over (B,S,ns).
 """
 from typing import List
 
@@ -16,6 +28,7 @@ import torch.nn.functional as F
 from torch.nn.utils import spectral_norm
 
 from . import ops
+from .graph_conv import amp_dtype, no_autocast, reference_order, rows_first  # noqa: F401
 
 
 def knn(k, xyz1, xyz2):
@@ -52,6 +65,45 @@ def build_shared_mlp(mlp_spec: List[int], bn: bool = True, sn: bool = True, act_
             layers.append(nn.BatchNorm2d(mlp_spec[i]))
         layers.append(act_fn)
     return nn.Sequential(*layers)
+
+
+def conv_weight2d(conv):
+    """(Cout,Cin) weight of a 1x1 conv AS THE MODULE CALL WOULD SEE IT: runs the module's
+    forward pre-hooks (old-style spectral norm: one power iteration in training mode and
+    `weight = weight_orig / sigma`, exactly once per forward as in the reference)."""
+    for hook in conv._forward_pre_hooks.values():
+        hook(conv, ())
+    return conv.weight.view(conv.weight.shape[0], -1)
+
+
+def bn_rows(bn, x):
+    """BatchNorm2d/1d module applied to rows (P,C): statistics over the P rows, i.e. over
+    (B,S,ns) of the reference's (B,C,S,ns) tensor; running stats and num_batches_tracked
+    updated exactly like the module's own forward."""
+    shape = x.shape
+    x = x.reshape(-1, shape[-1])
+    if bn.training and bn.track_running_stats and bn.num_batches_tracked is not None:
+        bn.num_batches_tracked.add_(1)
+    factor = 0.0 if bn.momentum is None else bn.momentum
+    if bn.momentum is None and bn.training and bn.track_running_stats:
+        factor = 1.0 / float(bn.num_batches_tracked)
+    use_batch_stats = bn.training or (bn.running_mean is None and bn.running_var is None)
+    y = F.batch_norm(x, bn.running_mean if not bn.training or bn.track_running_stats else None,
+                     bn.running_var if not bn.training or bn.track_running_stats else None,
+                     bn.weight, bn.bias, use_batch_stats, factor, bn.eps)
+    return y.view(shape)
+
+
+def mlp_tail_rows(layers, x):
+    """Run [conv, (bn), act]* layers (from a given position) on rows."""
+    for m in layers:
+        if isinstance(m, nn.Conv2d):
+            x = F.linear(x, conv_weight2d(m), m.bias)
+        elif isinstance(m, (nn.BatchNorm2d, nn.BatchNorm1d)):
+            x = bn_rows(m, x)
+        else:
+            x = m(x)
+    return x
 
 
 class QueryAndGroup(nn.Module):
@@ -125,9 +177,26 @@ class _PointnetSAModuleBase(nn.Module):
             centres = replace_dummy_centres(xyz, centres)
         return centres
 
-    def forward(self, xyz, features):
-        """xyz (B,N,3), features (B,C,N) -> new_xyz (B,npoint,3)|None, new_features (B,C',npoint)."""
-        xyz = xyz.contiguous()
+    def _first_layer(self, grouper, mlp, xyz, new_xyz, feat_rows):
+        """Rows of the first conv's output for every grouped position: (B,S,ns,C1)."""
+        conv = mlp[0]
+        with no_autocast(xyz):
+            W = conv_weight2d(conv).float()
+            src = xyz if feat_rows is None else torch.cat([xyz, feat_rows.float()], dim=-1)
+            if not grouper.use_xyz:
+                src = feat_rows.float()
+            if isinstance(grouper, GroupAll):
+                return F.linear(src, W, conv.bias).unsqueeze(1)    # one group holding all N points
+            U = F.linear(src, W, conv.bias)                         # (B,N,C1)
+            idx = ops.ball_query(grouper.radius, grouper.nsample, xyz, new_xyz)
+            if grouper.use_xyz:
+                Q = F.linear(new_xyz, W[:, :3])                     # centre term of (xyz_j - c_i)
+                return ops.row_combine(U, Q, idx, ops.ROW_SUB, out_dtype=amp_dtype(xyz))
+            return ops.row_combine(U, None, idx, ops.ROW_GATHER, out_dtype=amp_dtype(xyz))
+
+    def forward_rows(self, xyz, feat_rows):
+        """xyz (B,N,3), feat_rows (B,N,C)|None -> new_xyz (B,npoint,3)|None, (B,npoint,C') rows."""
+        xyz = xyz.float().contiguous()
         if self.npoint is not None:
             centres = self.sample_centres(xyz)
             new_xyz = ops.gather_operation(xyz.transpose(1, 2).contiguous(), centres)
@@ -136,9 +205,21 @@ class _PointnetSAModuleBase(nn.Module):
             new_xyz = None
         outs = []
         for grouper, mlp in zip(self.groupers, self.mlps):
-            g = mlp(grouper(xyz, new_xyz, features))               # (B,C',npoint,ns)
-            outs.append(F.max_pool2d(g, kernel_size=[1, g.size(3)]).squeeze(-1))
-        return new_xyz, torch.cat(outs, dim=1)
+            if rows_first():
+                y = self._first_layer(grouper, mlp, xyz, new_xyz, feat_rows)
+                y = mlp_tail_rows(list(mlp)[1:], y)                # (B,S,ns,C')
+                outs.append(y.max(dim=2)[0])
+            else:                                                  # discriminator.py:139-150
+                planes = None if feat_rows is None else feat_rows.float().transpose(1, 2).contiguous()
+                g = mlp(grouper(xyz, new_xyz, planes))             # (B,C',S,ns)
+                outs.append(F.max_pool2d(g, kernel_size=[1, g.size(3)]).squeeze(-1).transpose(1, 2))
+        return new_xyz, torch.cat(outs, dim=-1)
+
+    def forward(self, xyz, features):
+        """Reference signature: xyz (B,N,3), features (B,C,N) -> new_xyz, (B,C',npoint)."""
+        rows = None if features is None else features.transpose(1, 2)
+        new_xyz, out = self.forward_rows(xyz, rows)
+        return new_xyz, out.transpose(1, 2).contiguous()
 
 
 class MSGSetConv(_PointnetSAModuleBase):
@@ -185,17 +266,39 @@ class FlowEmbedding(nn.Module):
             self.mlp_bns.append(nn.BatchNorm2d(out_channel))
             last = out_channel
 
+    def forward_rows(self, p1, p2, f1, f2, radius):
+        """p (B,N,3), f (B,N,C) rows -> (B,N,mlp[-1]) rows.
+
+        First conv on cat([pos2_j - pos1_i, feat2_j, feat1_i]) (discriminator.py:270-280) split
+        by input columns: U = W[:, :3+C] [pos2|feat2] is gathered, Q = W[:, :3] pos1 - W[:, 3+C:] feat1
+        is the per-centre term."""
+        C = f1.shape[-1]
+        idx = ball_query_wrapper(radius, self.NSAMPLE, p1, p2).to(torch.int32).contiguous()
+        if not rows_first():                         # discriminator.py:270-283
+            B, N, _ = p1.shape
+            pos1, pos2 = p1.transpose(1, 2).contiguous(), p2.transpose(1, 2).contiguous()
+            pos_diff = ops.grouping_operation(pos2.float(), idx) - pos1.view(B, -1, N, 1)
+            feat2 = ops.grouping_operation(f2.float().transpose(1, 2).contiguous(), idx)
+            feat1 = f1.transpose(1, 2).reshape(B, -1, N, 1).expand(-1, -1, -1, self.NSAMPLE)
+            x = torch.cat([pos_diff, feat2, feat1], dim=1)
+            for conv, bn in zip(self.mlp_convs, self.mlp_bns):
+                x = F.leaky_relu(bn(conv(x)))
+            return torch.max(x, -1)[0].transpose(1, 2)
+        with no_autocast(p1):
+            W = conv_weight2d(self.mlp_convs[0]).float()
+            U = F.linear(torch.cat([p2.float(), f2.float()], dim=-1), W[:, :3 + C])
+            Q = F.linear(p1.float(), W[:, :3]) - F.linear(f1.float(), W[:, 3 + C:])
+        x = ops.row_combine(U, Q, idx, ops.ROW_SUB, out_dtype=amp_dtype(p1))     # (B,N,32,C1)
+        x = F.leaky_relu(bn_rows(self.mlp_bns[0], x))
+        for conv, bn in zip(list(self.mlp_convs)[1:], list(self.mlp_bns)[1:]):
+            x = F.leaky_relu(bn_rows(bn, F.linear(x, conv_weight2d(conv))))
+        return x.max(dim=2)[0]
+
     def forward(self, pos1, pos2, feature1, feature2, radius):
-        """pos (B,3,N), feature (B,C,N) -> pos1, (B,mlp[-1],N)."""
-        B, _, N = pos1.shape
-        idx = ball_query_wrapper(radius, self.NSAMPLE, pos1.transpose(1, 2), pos2.transpose(1, 2))
-        idx = idx.to(torch.int32).contiguous()
-        pos_diff = ops.grouping_operation(pos2.float().contiguous(), idx) - pos1.view(B, -1, N, 1)
-        feat2 = ops.grouping_operation(feature2.float().contiguous(), idx)
-        x = torch.cat([pos_diff, feat2, feature1.view(B, -1, N, 1).expand(-1, -1, -1, self.NSAMPLE)], dim=1)
-        for conv, bn in zip(self.mlp_convs, self.mlp_bns):
-            x = F.leaky_relu(bn(conv(x)))
-        return pos1, torch.max(x, -1)[0]
+        """Reference signature: pos (B,3,N), feature (B,C,N) -> pos1, (B,mlp[-1],N)."""
+        out = self.forward_rows(pos1.transpose(1, 2).contiguous(), pos2.transpose(1, 2).contiguous(),
+                                feature1.transpose(1, 2), feature2.transpose(1, 2), radius)
+        return pos1, out.transpose(1, 2).contiguous()
 
 
 class FlowModule(nn.Module):
@@ -216,15 +319,22 @@ class FlowModule(nn.Module):
                 spec = (hidden_feat, [hidden_feat, hidden_feat // 2, hidden_feat])
             self.flow_emb_layers.append(FlowEmbedding(spec[0], spec[1], sn=sn))
 
-    def forward(self, feature_lst, pos_lst, cutoff):
-        assert len(feature_lst) == self.depth + 1
-        feats = list(feature_lst)
+    def forward_rows(self, feat_rows_lst, pos_rows_lst, cutoff):
+        """Lists of (B,N,C) / (B,N,3) rows -> (B,N,out) rows."""
+        assert len(feat_rows_lst) == self.depth + 1
+        feats = list(feat_rows_lst)
         for depth in range(self.depth):
             layer = self.flow_emb_layers[depth]
-            feats = [layer(pos_lst[l].contiguous(), pos_lst[l + 1].contiguous(), feats[l].contiguous(),
-                           feats[l + 1].contiguous(), cutoff)[1] for l in range(len(feats) - 1)]
+            feats = [layer.forward_rows(pos_rows_lst[l], pos_rows_lst[l + 1], feats[l], feats[l + 1], cutoff)
+                     for l in range(len(feats) - 1)]
         assert len(feats) == 1
         return feats[0]
+
+    def forward(self, feature_lst, pos_lst, cutoff):
+        """Reference signature: lists of (B,C,N) / (B,3,N) -> (B,out,N)."""
+        out = self.forward_rows([f.transpose(1, 2) for f in feature_lst],
+                                [p.transpose(1, 2).contiguous() for p in pos_lst], cutoff)
+        return out.transpose(1, 2).contiguous()
 
 
 def _head(dims, drops):
@@ -246,24 +356,23 @@ class _TempoDis(nn.Module):
     def _levels(self, pos_lst, feat_lst):
         feats, poss = [], []
         for i, pos in enumerate(pos_lst):
-            f0 = (feat_lst[i] if feat_lst is not None else pos).transpose(1, 2).contiguous()
-            p1, f1 = self.coarse_graining_module[0](pos, f0)
+            p1, f1 = self.coarse_graining_module[0].forward_rows(pos, feat_lst[i] if feat_lst is not None else pos)
             poss.append(p1)
             feats.append(f1)
         feats2, poss2 = [], []
         for f, p in zip(feats, poss):
-            p2, f2 = self.coarse_graining_module[1](p, f)
+            p2, f2 = self.coarse_graining_module[1].forward_rows(p, f)
             feats2.append(f2)
-            poss2.append(p2.permute(0, 2, 1))                      # (B,3,N) for FlowEmbedding
+            poss2.append(p2)
         return feats2, poss2
 
     def _forward(self, pos_lst, cutoff, feat_lst, width):
         if feat_lst is not None:
             assert len(feat_lst) == len(pos_lst)
-        feats, poss = self._levels(pos_lst, feat_lst)
-        f = self.flow_module(feats, poss, self.flow_radius_scale * cutoff)
-        _, f = self.SA_pooling(poss[0].permute(0, 2, 1), f)
-        return self.fc_layers(f.view(-1, width))
+        feats, poss = self._levels(pos_lst, feat_lst)               # rows all the way
+        f = self.flow_module.forward_rows(feats, poss, self.flow_radius_scale * cutoff)
+        _, f = self.SA_pooling.forward_rows(poss[0], f)
+        return self.fc_layers(f.reshape(-1, width))
 
 
 class ActionTempoDis(_TempoDis):
@@ -302,9 +411,9 @@ class _SpatialDis(nn.Module):
     def _forward(self, pos, width):
         feature = None
         for sa in self.coarse_graining_module:
-            pos, feature = sa(pos, pos.transpose(1, 2).contiguous() if feature is None else feature)
-        _, feature = self.SA_pooling(pos, feature)
-        return self.fc_layers(feature.view(-1, width))
+            pos, feature = sa.forward_rows(pos, pos if feature is None else feature)
+        _, feature = self.SA_pooling.forward_rows(pos, feature)
+        return self.fc_layers(feature.reshape(-1, width))
 
 
 class ActionSpatialDis(_SpatialDis):

@@ -9,7 +9,8 @@ no norm layers), which is how the train step uses it on MI355X.
 import torch
 import torch.nn as nn
 
-from .graph_conv import EdgeConv, IDGCNLayer, build_shared_mlp, conv_bn_layer
+from .graph_conv import (EdgeConv, IDGCNLayer, build_shared_mlp, conv_bn_layer, rows_first, rows_linear,
+                         rows_seq)
 
 
 class GCNFeatureExtractor(nn.Module):
@@ -27,8 +28,23 @@ class GCNFeatureExtractor(nn.Module):
                 self.conv_layers.append(IDGCNLayer(node_emb_dim, node_emb_dim, bn=False, insn=False,
                                                    ln=False, residual=True))
 
+    def forward_rows(self, feature, pos=None):
+        """feature (B,N,C) [, pos (B,N,3)] -> (B,N,C') rows (the build's internal layout)."""
+        x = feature
+        outs = []
+        for l, layer in enumerate(self.conv_layers):
+            if l == 0:
+                x = layer.forward_rows(x, pos)
+            else:
+                x = layer.forward_rows(x)
+                outs.append(x)
+        return torch.cat(outs, dim=-1)
+
     def forward(self, feature, pos=None):
-        x = feature.permute(0, 2, 1).contiguous()                  # (B,C,N)
+        """Reference signature: (B,N,C) -> (B,C',N,1)."""
+        if rows_first():
+            return self.forward_rows(feature, pos).transpose(1, 2).unsqueeze(-1)
+        x = feature.permute(0, 2, 1).contiguous()                  # reference order, (B,C,N) planes
         outs = []
         for l, layer in enumerate(self.conv_layers):
             if l == 0:
@@ -36,7 +52,7 @@ class GCNFeatureExtractor(nn.Module):
             else:
                 x = layer(x)
                 outs.append(x)
-        return torch.cat(outs, dim=1)                              # (B,C',N,1)
+        return torch.cat(outs, dim=1)
 
 
 def _head_layers(width, make_last_edgeconv):
@@ -63,10 +79,19 @@ class UpsamplingModule(nn.Module):
             build_shared_mlp([w, out_dim // 2, out_dim], norm="none"),
             nn.Conv2d(out_dim, out_dim, 1, 1, 0, bias=True))
 
+    def forward_rows(self, x):
+        """(B,N,C) rows -> (B,N,3r)."""
+        for layer in self.upsample_layers:
+            x = layer.forward_rows(x) if isinstance(layer, EdgeConv) else rows_seq(layer, x)
+        return rows_linear(self.decoder[1], rows_seq(self.decoder[0], x))
+
     def forward(self, feature):
+        """Reference signature: (B,C,N,1) -> (B,N,3r)."""
+        if rows_first():
+            return self.forward_rows(feature.squeeze(-1).transpose(1, 2))
         for layer in self.upsample_layers:
             feature = layer(feature)
-        return self.decoder(feature).squeeze(-1).permute(0, 2, 1).contiguous()   # (B,N,3r)
+        return self.decoder(feature).squeeze(-1).permute(0, 2, 1).contiguous()
 
 
 class BinaryMaskingModule(nn.Module):
@@ -81,10 +106,19 @@ class BinaryMaskingModule(nn.Module):
             build_shared_mlp([w, w // 2, w // 4], norm="none"),
             nn.Conv2d(w // 4, 1, 1, 1, 0, bias=True))
 
+    def forward_rows(self, x):
+        """(B,N,C) rows -> (B,N,1)."""
+        for layer in self.upsample_layers:
+            x = layer.forward_rows(x) if isinstance(layer, EdgeConv) else rows_seq(layer, x)
+        return torch.relu(rows_linear(self.decoder[1], rows_seq(self.decoder[0], x)))
+
     def forward(self, feature):
+        """Reference signature: (B,C,N,1) -> (B,N,1)."""
+        if rows_first():
+            return self.forward_rows(feature.squeeze(-1).transpose(1, 2))
         for layer in self.upsample_layers:
             feature = layer(feature)
-        return torch.relu(self.decoder(feature)).squeeze(-1).permute(0, 2, 1).contiguous()  # (B,N,1)
+        return torch.relu(self.decoder(feature)).squeeze(-1).permute(0, 2, 1).contiguous()
 
 
 class SRNet(nn.Module):
@@ -104,8 +138,11 @@ class SRNet(nn.Module):
 
     # -- network body: everything up to (offsets, mask); batch rows are independent ----------
     def body(self, feature, pos):
+        if rows_first():
+            enc = self.feature_extractor.forward_rows(feature, pos if self.in_feats > 3 else None)
+            return self.upsampling_block.forward_rows(enc).float(), self.filter_block.forward_rows(enc).float()
         enc = self.feature_extractor(feature, pos) if self.in_feats > 3 else self.feature_extractor(feature)
-        return self.upsampling_block(enc), self.filter_block(enc)
+        return self.upsampling_block(enc).float(), self.filter_block(enc).float()
 
     def expand_pos_with_masking(self, pos, upsample_edge, binary_mask, hard_masking=False):
         """upsampling_network.py:131-157.  Returns (unpadded_pos, padded_or_compressed_pos|None)."""
@@ -152,9 +189,7 @@ class SRNet(nn.Module):
 
     def forward_with_context(self, feature, pos, previous_mask):
         """Rollout with a 25-frame running mask average (upsampling_network.py:159-174)."""
-        enc = self.feature_extractor(feature)
-        edge = self.upsampling_block(enc)
-        mask = self.filter_block(enc)
+        edge, mask = self.body(feature, None if self.in_feats <= 3 else pos)
         mask = torch.where(mask < 0.6, torch.zeros_like(mask), mask)
         mask = torch.where(mask > 0.6, torch.full_like(mask, 0.6), mask)
         if len(previous_mask) >= 25:
@@ -174,6 +209,11 @@ class NoMaskSRNet(nn.Module):
         self.upsampling_block = UpsamplingModule(node_emb_dim * (feature_extractor_depth - 1), upsample_ratio)
         self.upsample_ratio = upsample_ratio
 
+    def body(self, feature):
+        if rows_first():
+            return self.upsampling_block.forward_rows(self.feature_extractor.forward_rows(feature)).float()
+        return self.upsampling_block(self.feature_extractor(feature)).float()
+
     def expand_pos(self, pos, upsample_edge):
         B = pos.shape[0]
         return pos.repeat(1, 1, self.upsample_ratio).view(B, -1, 3) + upsample_edge.view(B, -1, 3)
@@ -183,13 +223,13 @@ class NoMaskSRNet(nn.Module):
             feature = feature.unsqueeze(0)
         if pos.dim() == 2:
             pos = pos.unsqueeze(0)
-        edge = self.upsampling_block(self.feature_extractor(feature))
+        edge = self.body(feature)
         out = self.expand_pos(pos, edge)
         return out, edge.view(out.shape[0], -1, 3)
 
     def forward_frames(self, features, positions):
         T, B = len(positions), positions[0].shape[0]
-        edge = self.upsampling_block(self.feature_extractor(torch.cat(features, 0)))
+        edge = self.body(torch.cat(features, 0))
         outs = []
         for t in range(T):
             e = edge[t * B:(t + 1) * B]

@@ -249,3 +249,60 @@ def test_full_size_properties_cfg2(hip):
     d1, i1, d2, i2 = hip.chamfer_fwd(xd, xd)
     assert (d1 == 0).all() and (d2 == 0).all()
     assert torch.equal(i1, torch.arange(4096, device="cuda").expand(8, -1))
+
+
+# ------------------------------------------------------------------ row combine (channels-last)
+def _bf16_round(a):
+    return torch.from_numpy(np.ascontiguousarray(a)).bfloat16().float().numpy()
+
+
+@pytest.mark.parametrize("mode", [0, 1, 2])
+@pytest.mark.parametrize("B,N,S,K,C", [(2, 512, 512, 20, 64), (2, 1024, 512, 32, 128), (1, 100, 100, 7, 8),
+                                       (3, 256, 256, 32, 256), (1, 4096, 1024, 32, 16)])
+@pytest.mark.parametrize("din,dout", [("f32", "f32"), ("bf16", "bf16"), ("f32", "bf16")])
+def test_rowcombine_fwd_exact_bwd_close(hip, mode, B, N, S, K, C, din, dout):
+    if mode == 2:
+        S = N
+    tdt = {"f32": torch.float32, "bf16": torch.bfloat16}
+    rng = np.random.default_rng(mode * 7 + C + K)
+    U = rng.standard_normal((B, N, C)).astype(np.float32)
+    Q = rng.standard_normal((B, S, C)).astype(np.float32)
+    idx = rng.integers(0, N, (B, S, K)).astype(np.int32)
+    idx[0, 0, :] = 3                      # one heavily repeated destination
+    if din == "bf16":
+        U, Q = _bf16_round(U), _bf16_round(Q)
+    Ud, Qd = dev(U).to(tdt[din]), dev(Q).to(tdt[din])
+    out = hip.rowcombine_fwd(Ud, None if mode == 0 else Qd, dev(idx), mode, 0.2, tdt[dout])
+    ref = R.rowcombine_fwd(U, None if mode == 0 else Q, idx, mode, 0.2)
+    if dout == "bf16":
+        ref = _bf16_round(ref)
+    assert out.dtype == tdt[dout]
+    assert np.array_equal(out.float().cpu().numpy(), ref)          # one rounding, same arithmetic
+    g = rng.standard_normal((B, S, K, C)).astype(np.float32)
+    if dout == "bf16":
+        g = _bf16_round(g)
+    gU, gQ = hip.rowcombine_bwd(dev(g).to(tdt[dout]), dev(idx), Qd if mode == 2 else None, mode, N, 0.2,
+                                tdt[din])
+    rU, rQ = R.rowcombine_bwd(g, idx, Q if mode == 2 else None, mode, N, 0.2)
+    tol = TOL if din == "f32" else 1e-2   # bf16 gradients are rounded to 8 bits on store
+    assert gU.dtype == tdt[din]
+    assert np.abs(gU.float().cpu().numpy() - rU).max() <= tol * max(1.0, np.abs(rU).max())
+    if mode:
+        assert np.abs(gQ.float().cpu().numpy() - rQ).max() <= tol * max(1.0, np.abs(rQ).max())
+    else:
+        assert gQ is None
+
+
+def test_invert_index_is_a_grouped_permutation(hip):
+    rng = np.random.default_rng(2)
+    B, N, SK = 3, 1000, 7777
+    idx = rng.integers(0, N, (B, SK)).astype(np.int32)
+    idx[1, :] = 5                         # every entry on one destination
+    offs, lst = hip.invert_index(dev(idx).view(B, SK, 1), N)
+    offs, lst = offs.cpu().numpy(), lst.cpu().numpy()
+    for b in range(B):
+        assert offs[b, 0] == 0 and offs[b, N] == SK and (np.diff(offs[b]) >= 0).all()
+        assert np.array_equal(np.sort(lst[b]), np.arange(SK))
+        assert np.array_equal(np.diff(offs[b]), np.bincount(idx[b], minlength=N))
+        dest = np.repeat(np.arange(N), np.diff(offs[b]))
+        assert np.array_equal(idx[b][lst[b]], dest)
