@@ -10,6 +10,10 @@ if ROOT not in sys.path:
 
 def pytest_configure(config):
     config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
+    # same setting as bench.py / smoke(): GEMMs go to hipBLASLt, BatchNorm to PyTorch's native
+    # kernels; MIOpen would JIT-compile one kernel per new shape on a fresh box.
+    import torch
+    torch.backends.cudnn.enabled = False
 
 
 @pytest.fixture(scope="session")
