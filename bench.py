@@ -72,10 +72,13 @@ def run_steps(models, clips, n, sync, amp_dtype, start=0):
 
 def cpu_baseline(sample_batch, per_gpu_batch, n_hi):
     """Time ONE step of the same workload on the host cores (oracle ops + CPU PyTorch)."""
+    # threads = the cores this process may actually run on (a GPU box hands each job a share)
+    cores = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+    cores = max(1, min(cores, int(os.environ.get("TPGAN_CPU_THREADS", "16"))))
+    os.environ["OMP_NUM_THREADS"] = str(cores)      # read by the oracle's OpenMP runtime at load
     from oracle import torch_backend
     torch_backend.install()
     try:
-        cores = os.cpu_count() or 1
         torch.set_num_threads(cores)
         np.random.seed(0)
         models = build("cpu")

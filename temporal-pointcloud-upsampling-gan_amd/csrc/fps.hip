@@ -8,10 +8,12 @@
 //     in REGISTERS for the whole kernel (PPT points per thread, compile-time),
 //     so a round touches no HBM and no LDS for point data except the 12-byte
 //     broadcast read of the last selected point from an LDS copy of the cloud;
-//   * per-lane candidate -> 64-bit key ((dist_bits+1) << 32 | ~idx): unsigned
-//     max == arg-max with ties to the smallest index (the canonical rule);
-//   * wave reduction by DPP (no LDS traffic), then ONE barrier per round: each
-//     wave drops its key into a double-buffered LDS slot and every wave
+//   * the round is branch-free: running distances live as float bits compared
+//     as ints, with -1.0f marking points that are never eligible;
+//   * arg-max with ties to the smallest index (the canonical rule) = integer
+//     max of the value, then min over the indices attaining it: two 32-bit DPP
+//     wave reductions (no LDS traffic), then ONE barrier per round: each wave
+//     drops its (value, index) into a double-buffered LDS slot and every wave
 //     re-reduces the <=16 slots redundantly, so no second barrier and no
 //     broadcast step are needed;
 //   * clouds of <=256 points run in a single wave with no barrier at all.
@@ -27,13 +29,17 @@ __device__ __forceinline__ tpg_u64 fps_key(float d2, int k) {
     return ((tpg_u64)(__float_as_uint(d2) + 1u) << 32) | (unsigned)(~k);
 }
 
-template <int BLOCK, int PPT>
+// Running distances are kept as float BITS compared as signed ints: every distance is >= +0,
+// whose bit patterns order like ints, and the single negative value -1.0f marks "not eligible"
+// (|x|^2 <= 1e-3, or padding) -- min(d, -1) stays -1 and -1 never beats the initial best = -1,
+// which is exactly the reference's `continue`.
+template <int BLOCK, int PPT, bool USE_LDS>
 __global__ __launch_bounds__(BLOCK) void fps_kernel(const float *__restrict__ xyz, int N, int m,
-                                                    int32_t *__restrict__ idx, int use_lds) {
+                                                    int32_t *__restrict__ idx) {
     extern __shared__ __attribute__((aligned(16))) float fps_smem[];
     constexpr int NW = BLOCK / 64;
-    // layout: [2][16] u64 slots (256 B), then SoA copy of the cloud (if it fits)
-    tpg_u64 *slots = reinterpret_cast<tpg_u64 *>(fps_smem);
+    // layout: [2][16] (value,index) slots (256 B), then SoA copy of the cloud (USE_LDS)
+    int2 *slots = reinterpret_cast<int2 *>(fps_smem);
     float *sx = fps_smem + 64;
     float *sy = sx + N;
     float *sz = sy + N;
@@ -45,7 +51,6 @@ __global__ __launch_bounds__(BLOCK) void fps_kernel(const float *__restrict__ xy
     int32_t *out = idx + (size_t)blockIdx.x * m;
 
     float px[PPT], py[PPT], pz[PPT], tp[PPT];
-    bool ok[PPT];
 #pragma unroll
     for (int t = 0; t < PPT; ++t) {
         const int k = tid + t * BLOCK;
@@ -56,46 +61,43 @@ __global__ __launch_bounds__(BLOCK) void fps_kernel(const float *__restrict__ xy
         float mag = px[t] * px[t];
         mag = mag + py[t] * py[t];
         mag = mag + pz[t] * pz[t];
-        ok[t] = in && (mag > 1e-3f);
-        tp[t] = 1e10f;
-        if (use_lds && in) { sx[k] = px[t]; sy[k] = py[t]; sz[k] = pz[t]; }
+        tp[t] = (in && mag > 1e-3f) ? 1e10f : -1.0f;
+        if (USE_LDS && in) { sx[k] = px[t]; sy[k] = py[t]; sz[k] = pz[t]; }
     }
     if (tid == 0) out[0] = 0;
-    if (NW > 1 || use_lds) __syncthreads();
+    if (NW > 1 || USE_LDS) __syncthreads();
 
     int old = 0;
     for (int j = 1; j < m; ++j) {
         float ox, oy, oz;
-        if (use_lds) { ox = sx[old]; oy = sy[old]; oz = sz[old]; }
+        if (USE_LDS) { ox = sx[old]; oy = sy[old]; oz = sz[old]; }
         else { ox = x[(size_t)old * 3]; oy = x[(size_t)old * 3 + 1]; oz = x[(size_t)old * 3 + 2]; }
 
-        float best = -1.0f;
+        int best = __float_as_int(-1.0f);
         int besti = 0;
 #pragma unroll
         for (int t = 0; t < PPT; ++t) {
             const float d = tpg_sq3(px[t], py[t], pz[t], ox, oy, oz);
             const float d2 = d < tp[t] ? d : tp[t];
-            if (ok[t]) {
-                tp[t] = d2;
-                if (d2 > best) { best = d2; besti = tid + t * BLOCK; }
-            }
+            tp[t] = d2;
+            const int b2 = __float_as_int(d2);
+            const bool up = b2 > best;            // strict: first (smallest) index wins inside a lane
+            best = up ? b2 : best;
+            besti = up ? tid + t * BLOCK : besti;
         }
-        tpg_u64 key = best >= 0.0f ? fps_key(best, besti) : 0ull;
-        key = tpg_wave_max_u64(key);
+        // arg-max with ties to the smallest index = max of the value, then min over the indices
+        // that attain it: two 32-bit DPP reductions.
+        int mx = tpg_wave_max_i32(best);
+        unsigned bi = tpg_wave_min_u32(best == mx ? (unsigned)besti : 0xffffffffu);
         if constexpr (NW > 1) {
-            tpg_u64 *slot = slots + (j & 1) * 16;
-            if (lane == 0) slot[wave] = key;
+            int2 *slot = slots + (j & 1) * 16;
+            if (lane == 0) slot[wave] = make_int2(mx, (int)bi);
             __syncthreads();
-            tpg_u64 v = lane < NW ? slot[lane] : 0ull;
-            // NW <= 16: reduce inside the first row of 16 lanes, then broadcast
-            tpg_u64 o;
-            o = tpg_dpp_u64<0xB1>(v); v = o > v ? o : v;
-            o = tpg_dpp_u64<0x4E>(v); v = o > v ? o : v;
-            o = tpg_dpp_u64<0x124>(v); v = o > v ? o : v;
-            o = tpg_dpp_u64<0x128>(v); v = o > v ? o : v;
-            key = tpg_readlane_u64(v, 0);
+            const int2 sv = lane < NW ? slot[lane] : make_int2((int)0x80000000, 0);
+            mx = tpg_row16_max_i32(sv.x);
+            bi = tpg_row16_min_u32(sv.x == mx ? (unsigned)sv.y : 0xffffffffu);
         }
-        old = key ? (int)(~(unsigned)key) : 0;
+        old = mx >= 0 ? (int)bi : 0;              // mx < 0 <=> no eligible point at all
         if (tid == 0) out[j] = old;
     }
 }
@@ -150,14 +152,16 @@ void fps_go(const float *xyz, int B, int N, int m, int32_t *idx, hipStream_t st)
     int use_lds = N <= FPS_LDS_POINTS;
     size_t smem = 256 + (use_lds ? sizeof(float) * 3 * (size_t)N : 0);
     if (smem > 48 * 1024 &&
-        hipFuncSetAttribute(reinterpret_cast<const void *>(&fps_kernel<BLOCK, PPT>),
+        hipFuncSetAttribute(reinterpret_cast<const void *>(&fps_kernel<BLOCK, PPT, true>),
                             hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem) != hipSuccess) {
         (void)hipGetLastError();
         use_lds = 0;  // read the selected point from L2 instead
         smem = 256;
     }
-    hipLaunchKernelGGL((fps_kernel<BLOCK, PPT>), dim3(B), dim3(BLOCK), smem, st, xyz, N, m, idx,
-                       use_lds);
+    if (use_lds)
+        hipLaunchKernelGGL((fps_kernel<BLOCK, PPT, true>), dim3(B), dim3(BLOCK), smem, st, xyz, N, m, idx);
+    else
+        hipLaunchKernelGGL((fps_kernel<BLOCK, PPT, false>), dim3(B), dim3(BLOCK), smem, st, xyz, N, m, idx);
 }
 
 }  // namespace

@@ -65,6 +65,51 @@ __device__ __forceinline__ tpg_u64 tpg_wave_min_u64(tpg_u64 v) {
     return ~tpg_wave_max_u64(~v);
 }
 
+// 32-bit wave reductions in the INTEGER domain (no float canonicalisation; the DPP move
+// folds into v_max_i32_dpp / v_min_u32_dpp).  Full-row steps use bound_ctrl with old = 0
+// (every lane is written), the two row_bcast steps keep the accumulator in unwritten rows.
+template <int CTRL>
+__device__ __forceinline__ int tpg_dpp_full(int v) {
+    return __builtin_amdgcn_update_dpp(0, v, CTRL, 0xF, 0xF, true);
+}
+template <int CTRL, int ROW_MASK>
+__device__ __forceinline__ int tpg_dpp_rows(int v) {
+    return __builtin_amdgcn_update_dpp(v, v, CTRL, ROW_MASK, 0xF, false);
+}
+__device__ __forceinline__ int tpg_wave_max_i32(int v) {
+    v = max(v, tpg_dpp_full<0xB1>(v));
+    v = max(v, tpg_dpp_full<0x4E>(v));
+    v = max(v, tpg_dpp_full<0x124>(v));
+    v = max(v, tpg_dpp_full<0x128>(v));
+    v = max(v, tpg_dpp_rows<0x142, 0xA>(v));
+    v = max(v, tpg_dpp_rows<0x143, 0xC>(v));
+    return __builtin_amdgcn_readlane(v, 63);
+}
+__device__ __forceinline__ unsigned tpg_wave_min_u32(unsigned v) {
+    v = min(v, (unsigned)tpg_dpp_full<0xB1>((int)v));
+    v = min(v, (unsigned)tpg_dpp_full<0x4E>((int)v));
+    v = min(v, (unsigned)tpg_dpp_full<0x124>((int)v));
+    v = min(v, (unsigned)tpg_dpp_full<0x128>((int)v));
+    v = min(v, (unsigned)tpg_dpp_rows<0x142, 0xA>((int)v));
+    v = min(v, (unsigned)tpg_dpp_rows<0x143, 0xC>((int)v));
+    return (unsigned)__builtin_amdgcn_readlane((int)v, 63);
+}
+// same, over the first 16 lanes only (one DPP row); result read from lane 0
+__device__ __forceinline__ int tpg_row16_max_i32(int v) {
+    v = max(v, tpg_dpp_full<0xB1>(v));
+    v = max(v, tpg_dpp_full<0x4E>(v));
+    v = max(v, tpg_dpp_full<0x124>(v));
+    v = max(v, tpg_dpp_full<0x128>(v));
+    return __builtin_amdgcn_readlane(v, 0);
+}
+__device__ __forceinline__ unsigned tpg_row16_min_u32(unsigned v) {
+    v = min(v, (unsigned)tpg_dpp_full<0xB1>((int)v));
+    v = min(v, (unsigned)tpg_dpp_full<0x4E>((int)v));
+    v = min(v, (unsigned)tpg_dpp_full<0x124>((int)v));
+    v = min(v, (unsigned)tpg_dpp_full<0x128>((int)v));
+    return (unsigned)__builtin_amdgcn_readlane((int)v, 0);
+}
+
 // clamp an index into [0, n) -- invalid indices are undefined behaviour upstream;
 // here they must never fault the GPU.
 __device__ __forceinline__ int tpg_clamp_idx(int id, int n) {

@@ -108,22 +108,30 @@ class _DeviceGuard:
 
 
 class HipBackend:
-    """Raw (non-autograd) ops on HIP tensors through the C-ABI."""
+    """Raw (non-autograd) ops on HIP tensors through the C-ABI (include/tpgan_ops.h).
+
+    Every method allocates its outputs with torch, launches on torch's current stream and
+    returns without synchronising.  `_call` adds the optional per-kernel HIP-event timing
+    (algorithmic bytes per launch are the SURVEY.md section 8d figures)."""
 
     name = "hip"
 
     def __init__(self):
         self.lib = _lib.load()
 
+    def _call(self, symbol, op, nbytes, ref, *args):
+        fn = getattr(self.lib, symbol)
+        with _DeviceGuard(ref):
+            _lib.check(_run(op, nbytes, ref, lambda: fn(*args, _stream(ref))), symbol)
+
     def knn(self, p1, p2, len1, len2, K, r2):
         B, P1, D = p1.shape
         P2 = p2.shape[1]
         dist = torch.empty((B, P1, K), dtype=torch.float32, device=p1.device)
         idx = torch.empty((B, P1, K), dtype=torch.int64, device=p1.device)
-        with _DeviceGuard(p1):
-            _lib.check(_run("knn", 4 * B * D * (P1 + P2) + 12 * B * P1 * K, p1, lambda: self.lib.tpg_knn_f32(_ptr(p1), _ptr(p2), _ptr(len1), _ptr(len2), B, P1, P2, D, K,
-                                            -1.0 if r2 is None else r2, _ptr(dist), _ptr(idx),
-                                            _stream(p1))), "tpg_knn_f32")
+        self._call("tpg_knn_f32", "knn", 4 * B * D * (P1 + P2) + 12 * B * P1 * K, p1,
+                   _ptr(p1), _ptr(p2), _ptr(len1), _ptr(len2), B, P1, P2, D, K,
+                   -1.0 if r2 is None else r2, _ptr(dist), _ptr(idx))
         return dist, idx
 
     def chamfer_fwd(self, src, tgt):
@@ -133,73 +141,61 @@ class HipBackend:
         i1 = torch.empty((B, N), dtype=torch.int64, device=src.device)
         d2 = torch.empty((B, M), dtype=torch.float32, device=src.device)
         i2 = torch.empty((B, M), dtype=torch.int64, device=src.device)
-        with _DeviceGuard(src):
-            _lib.check(_run("chamfer_fwd", 24 * B * (N + M), src, lambda: self.lib.tpg_chamfer_fwd_f32(_ptr(src), _ptr(tgt), B, N, M, _ptr(d1), _ptr(i1),
-                                                    _ptr(d2), _ptr(i2), _stream(src))),
-                       "tpg_chamfer_fwd_f32")
+        self._call("tpg_chamfer_fwd_f32", "chamfer_fwd", 24 * B * (N + M), src,
+                   _ptr(src), _ptr(tgt), B, N, M, _ptr(d1), _ptr(i1), _ptr(d2), _ptr(i2))
         return d1, i1, d2, i2
 
     def chamfer_bwd(self, src, tgt, i1, i2, g1, g2):
         B, N, _ = src.shape
         M = tgt.shape[1]
         gs, gt = torch.empty_like(src), torch.empty_like(tgt)
-        with _DeviceGuard(src):
-            _lib.check(_run("chamfer_bwd", 40 * B * (N + M), src, lambda: self.lib.tpg_chamfer_bwd_f32(_ptr(src), _ptr(tgt), B, N, M, _ptr(i1), _ptr(i2),
-                                                    _ptr(g1), _ptr(g2), _ptr(gs), _ptr(gt),
-                                                    _stream(src))), "tpg_chamfer_bwd_f32")
+        self._call("tpg_chamfer_bwd_f32", "chamfer_bwd", 40 * B * (N + M), src,
+                   _ptr(src), _ptr(tgt), B, N, M, _ptr(i1), _ptr(i2), _ptr(g1), _ptr(g2), _ptr(gs), _ptr(gt))
         return gs, gt
 
     def fps(self, xyz, m):
         B, N, _ = xyz.shape
         idx = torch.empty((B, m), dtype=torch.int32, device=xyz.device)
         temp = torch.empty((B, N), dtype=torch.float32, device=xyz.device) if N > 16384 else None
-        with _DeviceGuard(xyz):
-            _lib.check(_run("fps", 12 * B * N + 4 * B * m, xyz, lambda: self.lib.tpg_fps_f32(_ptr(xyz), B, N, m, _ptr(temp), _ptr(idx), _stream(xyz))),
-                       "tpg_fps_f32")
+        self._call("tpg_fps_f32", "fps", 12 * B * N + 4 * B * m, xyz, _ptr(xyz), B, N, m, _ptr(temp), _ptr(idx))
         return idx
 
     def gather_fwd(self, feat, idx):
         B, Cc, N = feat.shape
         S = idx.shape[1]
         out = torch.empty((B, Cc, S), dtype=torch.float32, device=feat.device)
-        with _DeviceGuard(feat):
-            _lib.check(_run("gather_fwd", 4 * B * (Cc * N + S + Cc * S), feat, lambda: self.lib.tpg_gather_fwd_f32(_ptr(feat), _ptr(idx), B, Cc, N, S, _ptr(out),
-                                                   _stream(feat))), "tpg_gather_fwd_f32")
+        self._call("tpg_gather_fwd_f32", "gather_fwd", 4 * B * (Cc * N + S + Cc * S), feat,
+                   _ptr(feat), _ptr(idx), B, Cc, N, S, _ptr(out))
         return out
 
     def gather_bwd(self, gout, idx, N):
         B, Cc, S = gout.shape
         g = torch.empty((B, Cc, N), dtype=torch.float32, device=gout.device)
-        with _DeviceGuard(gout):
-            _lib.check(_run("gather_bwd", 4 * B * (Cc * N + S + Cc * S), gout, lambda: self.lib.tpg_gather_bwd_f32(_ptr(gout), _ptr(idx), B, Cc, N, S, _ptr(g),
-                                                   _stream(gout))), "tpg_gather_bwd_f32")
+        self._call("tpg_gather_bwd_f32", "gather_bwd", 4 * B * (Cc * N + S + Cc * S), gout,
+                   _ptr(gout), _ptr(idx), B, Cc, N, S, _ptr(g))
         return g
 
     def ball_query(self, radius, nsample, xyz, new_xyz):
         B, N, _ = xyz.shape
         S = new_xyz.shape[1]
         idx = torch.empty((B, S, nsample), dtype=torch.int32, device=xyz.device)
-        with _DeviceGuard(xyz):
-            _lib.check(_run("ball_query", 12 * B * (N + S) + 4 * B * S * nsample, xyz, lambda: self.lib.tpg_ball_query_f32(_ptr(xyz), _ptr(new_xyz), B, N, S, float(radius),
-                                                   nsample, _ptr(idx), _stream(xyz))),
-                       "tpg_ball_query_f32")
+        self._call("tpg_ball_query_f32", "ball_query", 12 * B * (N + S) + 4 * B * S * nsample, xyz,
+                   _ptr(xyz), _ptr(new_xyz), B, N, S, float(radius), nsample, _ptr(idx))
         return idx
 
     def group_fwd(self, feat, idx):
         B, Cc, N = feat.shape
         _, S, K = idx.shape
         out = torch.empty((B, Cc, S, K), dtype=torch.float32, device=feat.device)
-        with _DeviceGuard(feat):
-            _lib.check(_run("group_fwd", 4 * B * (Cc * N + S * K + Cc * S * K), feat, lambda: self.lib.tpg_group_fwd_f32(_ptr(feat), _ptr(idx), B, Cc, N, S, K, _ptr(out),
-                                                  _stream(feat))), "tpg_group_fwd_f32")
+        self._call("tpg_group_fwd_f32", "group_fwd", 4 * B * (Cc * N + S * K + Cc * S * K), feat,
+                   _ptr(feat), _ptr(idx), B, Cc, N, S, K, _ptr(out))
         return out
 
     def group_bwd(self, gout, idx, N):
         B, Cc, S, K = gout.shape
         g = torch.empty((B, Cc, N), dtype=torch.float32, device=gout.device)
-        with _DeviceGuard(gout):
-            _lib.check(_run("group_bwd", 4 * B * (Cc * N + S * K + Cc * S * K), gout, lambda: self.lib.tpg_group_bwd_f32(_ptr(gout), _ptr(idx), B, Cc, N, S, K, _ptr(g),
-                                                  _stream(gout))), "tpg_group_bwd_f32")
+        self._call("tpg_group_bwd_f32", "group_bwd", 4 * B * (Cc * N + S * K + Cc * S * K), gout,
+                   _ptr(gout), _ptr(idx), B, Cc, N, S, K, _ptr(g))
         return g
 
     def three_nn(self, unknown, known):
@@ -207,42 +203,35 @@ class HipBackend:
         m = known.shape[1]
         d2 = torch.empty((B, n, 3), dtype=torch.float32, device=unknown.device)
         idx = torch.empty((B, n, 3), dtype=torch.int32, device=unknown.device)
-        with _DeviceGuard(unknown):
-            _lib.check(self.lib.tpg_three_nn_f32(_ptr(unknown), _ptr(known), B, n, m, _ptr(d2), _ptr(idx),
-                                                 _stream(unknown)), "tpg_three_nn_f32")
+        self._call("tpg_three_nn_f32", "three_nn", 12 * B * (n + m) + 24 * B * n, unknown,
+                   _ptr(unknown), _ptr(known), B, n, m, _ptr(d2), _ptr(idx))
         return d2, idx
 
     def three_interp_fwd(self, feat, idx, w):
         B, Cc, m = feat.shape
         n = idx.shape[1]
         out = torch.empty((B, Cc, n), dtype=torch.float32, device=feat.device)
-        with _DeviceGuard(feat):
-            _lib.check(self.lib.tpg_three_interp_fwd_f32(_ptr(feat), _ptr(idx), _ptr(w), B, Cc, m, n,
-                                                         _ptr(out), _stream(feat)),
-                       "tpg_three_interp_fwd_f32")
+        self._call("tpg_three_interp_fwd_f32", "three_interp_fwd", 4 * B * (Cc * m + 6 * n + Cc * n), feat,
+                   _ptr(feat), _ptr(idx), _ptr(w), B, Cc, m, n, _ptr(out))
         return out
 
     def three_interp_bwd(self, gout, idx, w, m):
         B, Cc, n = gout.shape
         g = torch.empty((B, Cc, m), dtype=torch.float32, device=gout.device)
-        with _DeviceGuard(gout):
-            _lib.check(self.lib.tpg_three_interp_bwd_f32(_ptr(gout), _ptr(idx), _ptr(w), B, Cc, m, n,
-                                                         _ptr(g), _stream(gout)),
-                       "tpg_three_interp_bwd_f32")
+        self._call("tpg_three_interp_bwd_f32", "three_interp_bwd", 4 * B * (Cc * m + 6 * n + Cc * n), gout,
+                   _ptr(gout), _ptr(idx), _ptr(w), B, Cc, m, n, _ptr(g))
         return g
-
 
     # ---- channels-last row combine (csrc/rowgather.hip) --------------------------------
     def rowcombine_fwd(self, U, QE, idx, mode, slope, out_dtype):
         B, N, Cc = U.shape
         _, S, K = idx.shape
         out = torch.empty((B, S, K, Cc), dtype=out_dtype, device=U.device)
-        nbytes = U.element_size() * B * Cc * (N + (S if QE is not None else 0)) + 4 * B * S * K \
-            + out.element_size() * B * S * K * Cc
-        with _DeviceGuard(U):
-            _lib.check(_run("rowcombine_fwd", nbytes, U, lambda: self.lib.tpg_rowcombine_fwd(
-                _ptr(U), _ptr(QE), _ptr(idx), mode, _DTYPE_CODE[U.dtype], _DTYPE_CODE[out_dtype], B, N, S, K,
-                Cc, float(slope), _ptr(out), _stream(U))), "tpg_rowcombine_fwd")
+        nbytes = (U.element_size() * B * Cc * (N + (S if QE is not None else 0)) + 4 * B * S * K
+                  + out.element_size() * B * S * K * Cc)
+        self._call("tpg_rowcombine_fwd", "rowcombine_fwd", nbytes, U,
+                   _ptr(U), _ptr(QE), _ptr(idx), mode, _DTYPE_CODE[U.dtype], _DTYPE_CODE[out_dtype],
+                   B, N, S, K, Cc, float(slope), _ptr(out))
         return out
 
     def invert_index(self, idx, N):
@@ -250,9 +239,8 @@ class HipBackend:
         SK = idx[0].numel()
         offs = torch.empty((B, N + 1), dtype=torch.int32, device=idx.device)
         lst = torch.empty((B, SK), dtype=torch.int32, device=idx.device)
-        with _DeviceGuard(idx):
-            _lib.check(_run("invert_index", 4 * B * (2 * SK + N + 1), idx, lambda: self.lib.tpg_invert_index(
-                _ptr(idx), B, N, SK, _ptr(offs), _ptr(lst), _stream(idx))), "tpg_invert_index")
+        self._call("tpg_invert_index", "invert_index", 4 * B * (2 * SK + N + 1), idx,
+                   _ptr(idx), B, N, SK, _ptr(offs), _ptr(lst))
         return offs, lst
 
     def rowcombine_bwd(self, gout, idx, E, mode, N, slope, in_dtype):
@@ -260,13 +248,11 @@ class HipBackend:
         offs, lst = self.invert_index(idx, N)
         gU = torch.empty((B, N, Cc), dtype=in_dtype, device=gout.device)
         gQE = torch.empty((B, S, Cc), dtype=in_dtype, device=gout.device) if mode != 0 else None
-        nbytes = gout.element_size() * B * S * K * Cc * (2 if mode == 1 else 1) + 8 * B * S * K \
-            + gU.element_size() * B * Cc * (N + (S if mode else 0))
-        with _DeviceGuard(gout):
-            _lib.check(_run("rowcombine_bwd", nbytes, gout, lambda: self.lib.tpg_rowcombine_bwd(
-                _ptr(gout), _ptr(idx), _ptr(offs), _ptr(lst), _ptr(E), mode, _DTYPE_CODE[in_dtype],
-                _DTYPE_CODE[gout.dtype], B, N, S, K, Cc, float(slope), _ptr(gU), _ptr(gQE),
-                _stream(gout))), "tpg_rowcombine_bwd")
+        nbytes = (gout.element_size() * B * S * K * Cc * (2 if mode == 1 else 1) + 8 * B * S * K
+                  + gU.element_size() * B * Cc * (N + (S if mode else 0)))
+        self._call("tpg_rowcombine_bwd", "rowcombine_bwd", nbytes, gout,
+                   _ptr(gout), _ptr(idx), _ptr(offs), _ptr(lst), _ptr(E), mode, _DTYPE_CODE[in_dtype],
+                   _DTYPE_CODE[gout.dtype], B, N, S, K, Cc, float(slope), _ptr(gU), _ptr(gQE))
         return gU, gQE
 
 

@@ -215,6 +215,40 @@ class _PointnetSAModuleBase(nn.Module):
                 outs.append(F.max_pool2d(g, kernel_size=[1, g.size(3)]).squeeze(-1).transpose(1, 2))
         return new_xyz, torch.cat(outs, dim=-1)
 
+    def forward_rows_frames(self, xyz_lst, feat_rows_lst):
+        """T frames of one clip through this level: lists of (B,N,3) / (B,N,C) -> lists.
+
+        Exactly T separate `forward_rows` calls (per-frame spectral-norm power iterations,
+        per-frame BatchNorm statistics, same order of host RNG draws), except that the
+        index-only work -- FPS, centre gather, ball query, the row gather -- runs ONCE on the
+        T*B stacked clouds: those ops have no cross-cloud coupling, and FPS in particular is
+        a chain of npoint-1 dependent rounds whose latency is paid per launch, not per cloud."""
+        T = len(xyz_lst)
+        single = len(self.groupers) == 1 and isinstance(self.groupers[0], QueryAndGroup)
+        if T == 1 or not rows_first() or self.npoint is None or not single or not self.groupers[0].use_xyz:
+            outs = [self.forward_rows(x, f) for x, f in zip(xyz_lst, feat_rows_lst)]
+            return [o[0] for o in outs], [o[1] for o in outs]
+        B = xyz_lst[0].shape[0]
+        grouper, mlp = self.groupers[0], self.mlps[0]
+        xyz = torch.cat([x.float() for x in xyz_lst], 0).contiguous()
+        centres = self.sample_centres(xyz)
+        new_xyz = ops.gather_operation(xyz.transpose(1, 2).contiguous(), centres).transpose(1, 2).contiguous()
+        idx = ops.ball_query(grouper.radius, grouper.nsample, xyz, new_xyz)
+        conv = mlp[0]
+        Us, Qs = [], []
+        with no_autocast(xyz):
+            for t in range(T):
+                W = conv_weight2d(conv).float()                    # one power iteration per frame
+                sl = slice(t * B, (t + 1) * B)
+                f = feat_rows_lst[t]
+                src = xyz[sl] if f is None else torch.cat([xyz[sl], f.float()], dim=-1)
+                Us.append(F.linear(src, W, conv.bias))
+                Qs.append(F.linear(new_xyz[sl], W[:, :3]))
+        y = ops.row_combine(torch.cat(Us, 0), torch.cat(Qs, 0), idx, ops.ROW_SUB, out_dtype=amp_dtype(xyz))
+        tail = list(mlp)[1:]
+        feats = [mlp_tail_rows(tail, y[t * B:(t + 1) * B]).max(dim=2)[0] for t in range(T)]
+        return [new_xyz[t * B:(t + 1) * B] for t in range(T)], feats
+
     def forward(self, xyz, features):
         """Reference signature: xyz (B,N,3), features (B,C,N) -> new_xyz, (B,C',npoint)."""
         rows = None if features is None else features.transpose(1, 2)
@@ -354,16 +388,9 @@ class _TempoDis(nn.Module):
     flow_radius_scale = 1.0
 
     def _levels(self, pos_lst, feat_lst):
-        feats, poss = [], []
-        for i, pos in enumerate(pos_lst):
-            p1, f1 = self.coarse_graining_module[0].forward_rows(pos, feat_lst[i] if feat_lst is not None else pos)
-            poss.append(p1)
-            feats.append(f1)
-        feats2, poss2 = [], []
-        for f, p in zip(feats, poss):
-            p2, f2 = self.coarse_graining_module[1].forward_rows(p, f)
-            feats2.append(f2)
-            poss2.append(p2)
+        feats0 = list(feat_lst) if feat_lst is not None else list(pos_lst)
+        poss, feats = self.coarse_graining_module[0].forward_rows_frames(list(pos_lst), feats0)
+        poss2, feats2 = self.coarse_graining_module[1].forward_rows_frames(poss, feats)
         return feats2, poss2
 
     def _forward(self, pos_lst, cutoff, feat_lst, width):
