@@ -131,6 +131,28 @@ int tpg_rowcombine_bwd(const void *gout, const int32_t *idx, const int32_t *offs
                        const void *E, int mode, int dtype_in, int dtype_out, int B, int N, int S, int K,
                        int C, float slope, void *gU, void *gQE, void *stream);
 
+/* ---- fused BatchNorm + LeakyReLU (+ max over K neighbours) on channels-last rows ----------
+ * The [conv -> BatchNorm2d -> (Leaky)ReLU]* -> max-over-nsample tail of every shared MLP
+ * (discriminator.py:63-78,145-150,279-282) on rows x (P,C), P = B*S*ns:
+ *   z = (x - mean) * gamma * rstd + beta;  y = z > 0 ? z : slope*z   (slope 0 = ReLU, 1 = none)
+ *   K == 0: y (P,C).   K > 0: y (P/K,C) = max over each group of K consecutive rows, plus the
+ *   arg-max row of every (group, channel) as one byte (first maximum).
+ * training != 0: mean / rstd are computed from x (biased variance, eps) and written; running
+ * statistics (may be NULL) are updated with `momentum` and the unbiased variance.
+ * training == 0: mean / rstd are inputs (the caller derives them from the running statistics).
+ * ws: tpg_rowbn_workspace_bytes(C) bytes of scratch.  gamma / beta may be NULL (1 / 0). */
+size_t tpg_rowbn_workspace_bytes(int C);
+int tpg_rowbn_fwd(const void *x, int dtype_in, long long P, int K, int C, float eps, float momentum,
+                  int training, float *running_mean, float *running_var, const float *gamma,
+                  const float *beta, float slope, float *mean, float *rstd, void *y, int dtype_out,
+                  uint8_t *argmax, void *ws, void *stream);
+/* gy: (P,C) for K == 0, (P/K,C) for K > 0, of dtype_g; dx (P,C) of dtype_in; dgamma / dbeta (C) f32
+ * (may be NULL). */
+int tpg_rowbn_bwd(const void *gy, int dtype_g, const void *x, int dtype_in, const uint8_t *argmax,
+                  long long P, int K, int C, int training, const float *mean, const float *rstd,
+                  const float *gamma, const float *beta, float slope, float *dgamma, float *dbeta,
+                  void *dx, void *ws, void *stream);
+
 #ifdef __cplusplus
 }
 #endif

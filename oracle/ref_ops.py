@@ -189,3 +189,49 @@ def rowcombine_bwd(gout, idx, E, mode, N, slope=0.2):
                                          Cc, C.c_float(slope), _f(gU), None if gQE is None else _f(gQE)),
          "rowcombine_bwd")
     return gU, gQE
+
+
+# ---- fused BatchNorm + LeakyReLU (+ max over K) on rows: numpy restatement (float64 inside) of the
+# build's own fused form of [BatchNorm2d -> (Leaky)ReLU -> max over nsample]
+# (reference discriminator.py:63-78,145-150,279-282); equality with the reference is pinned at
+# model level by tests/golden.
+def rowbn_fwd(x, K, eps, gamma, beta, slope, training=True, mean=None, rstd=None):
+    x64 = np.asarray(x, np.float64)
+    P, Cc = x64.shape
+    if training:
+        mean = x64.mean(0)
+        var = x64.var(0)
+        rstd = 1.0 / np.sqrt(var + eps)
+    g = np.ones(Cc) if gamma is None else np.asarray(gamma, np.float64)
+    b = np.zeros(Cc) if beta is None else np.asarray(beta, np.float64)
+    z = (x64 - mean) * (g * rstd) + b
+    y = np.where(z > 0, z, z * slope)
+    arg = None
+    if K:
+        yk = y.reshape(P // K, K, Cc)
+        arg = yk.argmax(1).astype(np.uint8)          # first maximum
+        y = yk.max(1)
+    return y.astype(np.float32), np.asarray(mean, np.float32), np.asarray(rstd, np.float32), arg
+
+
+def rowbn_bwd(gy, x, arg, K, training, mean, rstd, gamma, beta, slope):
+    x64 = np.asarray(x, np.float64)
+    P, Cc = x64.shape
+    g_ = np.ones(Cc) if gamma is None else np.asarray(gamma, np.float64)
+    b_ = np.zeros(Cc) if beta is None else np.asarray(beta, np.float64)
+    mean, rstd = np.asarray(mean, np.float64), np.asarray(rstd, np.float64)
+    xhat = (x64 - mean) * rstd
+    z = xhat * g_ + b_
+    gy64 = np.asarray(gy, np.float64)
+    if K:
+        full = np.zeros((P // K, K, Cc))
+        gi, ci = np.meshgrid(np.arange(P // K), np.arange(Cc), indexing="ij")
+        full[gi, arg.astype(np.int64), ci] = gy64
+        gy64 = full.reshape(P, Cc)
+    g = gy64 * np.where(z > 0, 1.0, slope)
+    dbeta, dgamma = g.sum(0), (g * xhat).sum(0)
+    if training:
+        dx = g_ * rstd * (g - dbeta / P - xhat * dgamma / P)
+    else:
+        dx = g_ * rstd * g
+    return dx.astype(np.float32), dgamma.astype(np.float32), dbeta.astype(np.float32)

@@ -84,6 +84,27 @@ class OracleBackend:
         return _t(gU).to(in_dtype), (None if gQE is None else _t(gQE).to(in_dtype))
 
 
+    # ---- fused BatchNorm + act (+max) on rows ---------------------------------------------
+    def rowbn_fwd(self, x, K, eps, momentum, training, running_mean, running_var, gamma, beta, slope, mean,
+                  rstd, out_dtype):
+        y, m, r, arg = R.rowbn_fwd(_np(x.float()), K, eps, _np(gamma), _np(beta), slope, training,
+                                   None if training else _np(mean), None if training else _np(rstd))
+        if training:
+            mean.copy_(_t(m))
+            rstd.copy_(_t(r))
+            if running_mean is not None:
+                P = x.shape[0]
+                var = (1.0 / (_t(r).double() ** 2) - eps) * (P / max(P - 1, 1))
+                running_mean.mul_(1 - momentum).add_(momentum * _t(m))
+                running_var.mul_(1 - momentum).add_((momentum * var).float())
+        return _t(y).to(out_dtype), (None if arg is None else _t(arg))
+
+    def rowbn_bwd(self, gy, x, arg, K, training, mean, rstd, gamma, beta, slope, need_affine):
+        dx, dg, db = R.rowbn_bwd(_np(gy.float()), _np(x.float()), _np(arg), K, training, _np(mean), _np(rstd),
+                                 _np(gamma), _np(beta), slope)
+        return _t(dx).to(x.dtype), (_t(dg) if need_affine else None), (_t(db) if need_affine else None)
+
+
 def install():
     import tpgan_amd.ops as ops
     ops.register_backend("cpu", OracleBackend())

@@ -14,6 +14,7 @@ LIB_PATH = os.path.join(_HERE, "csrc", "libtpgan_hip.so")
 _P = C.c_void_p
 _I = C.c_int
 _F = C.c_float
+_L = C.c_longlong
 
 # symbol -> argtypes (restype is always int except the two string getters)
 SIGNATURES = {
@@ -32,7 +33,10 @@ SIGNATURES = {
     "tpg_rowcombine_fwd": [_P, _P, _P, _I, _I, _I, _I, _I, _I, _I, _I, _F, _P, _P],
     "tpg_invert_index": [_P, _I, _I, _I, _P, _P, _P],
     "tpg_rowcombine_bwd": [_P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _I, _I, _F, _P, _P, _P],
+    "tpg_rowbn_fwd": [_P, _I, _L, _I, _I, _F, _F, _I, _P, _P, _P, _P, _F, _P, _P, _P, _I, _P, _P, _P],
+    "tpg_rowbn_bwd": [_P, _I, _P, _I, _P, _L, _I, _I, _I, _P, _P, _P, _P, _F, _P, _P, _P, _P, _P],
 }
+SIZE_GETTERS = ("tpg_rowbn_workspace_bytes",)
 STRING_GETTERS = ("tpg_version", "tpg_target_arch")
 
 STATUS = {0: "TPG_OK", -1: "TPG_ERR_ARG", -2: "TPG_ERR_LAUNCH", -3: "TPG_ERR_UNSUPPORTED"}
@@ -60,6 +64,9 @@ def load():
         fn.restype = C.c_int
     for name in STRING_GETTERS:
         getattr(lib, name).restype = C.c_char_p
+    for name in SIZE_GETTERS:
+        getattr(lib, name).argtypes = [C.c_int]
+        getattr(lib, name).restype = C.c_size_t
     _lib = lib
     return lib
 

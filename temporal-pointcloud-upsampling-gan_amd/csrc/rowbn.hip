@@ -1,0 +1,462 @@
+// Fused training-mode BatchNorm + LeakyReLU (+ max over the K neighbours) on channels-last rows.
+//
+// Every shared-MLP layer of the discriminators is conv -> BatchNorm2d -> (Leaky)ReLU over a
+// (B,C,S,ns) tensor, and the last one is followed by a max over ns (reference
+// discriminator.py:63-78,145-150,279-282).  On rows (P = B*S*ns, C) that is
+//
+//   stats   : per-channel sum / sum of squares over the P rows            (1 read of x)
+//   apply   : y = lrelu(a*x + b), a = gamma*rstd, b = beta - mean*a       (1 read, 1 write)
+//             optionally reduced on the fly to max over each group of K consecutive rows,
+//             writing P/K rows and a one-byte arg-max per (group, channel)
+//   backward: g = gy * lrelu'(a*x+b);  dbeta = sum g, dgamma = sum g*xhat   (1 read of x,gy)
+//             dx = a * (g - dbeta/P - xhat*dgamma/P)                       (1 read, 1 write)
+//
+// i.e. 2+3 streaming passes at HBM rate instead of PyTorch's BatchNorm (stats + transform),
+// LeakyReLU, max-reduce and their three backward kernels.  Rows are 16-byte vectors per lane
+// (fp32 or bf16 storage, fp32 arithmetic); column sums use per-thread register accumulators
+// over a grid-stride of rows, one LDS tree per workgroup, and a deterministic two-stage
+// reduction (per-workgroup partials -> one finalize workgroup in fp64), so statistics are
+// bitwise reproducible run to run and there are no float atomics.  Sums are taken about a
+// per-channel pivot (the first row) to keep E[x^2]-E[x]^2 well conditioned.
+#include <hip/hip_bf16.h>
+
+#include "tpg_common.hpp"
+
+namespace {
+
+constexpr int BN_THREADS = 256;
+constexpr int BN_MAX_BLOCKS = 1024;  // partial rows per reduction (4 workgroups per CU)
+
+// ---- 16-byte row chunks <-> NE floats (same helpers as rowgather.hip) ----------------------
+template <typename T, int NE> struct BnIO;
+template <int NE> struct BnIO<float, NE> {
+    static __device__ __forceinline__ void load(const float *p, float (&v)[NE]) {
+#pragma unroll
+        for (int i = 0; i < NE / 4; ++i) {
+            const float4 x = reinterpret_cast<const float4 *>(p)[i];
+            v[4 * i] = x.x; v[4 * i + 1] = x.y; v[4 * i + 2] = x.z; v[4 * i + 3] = x.w;
+        }
+    }
+    static __device__ __forceinline__ void store(float *p, const float (&v)[NE]) {
+#pragma unroll
+        for (int i = 0; i < NE / 4; ++i)
+            reinterpret_cast<float4 *>(p)[i] = make_float4(v[4 * i], v[4 * i + 1], v[4 * i + 2], v[4 * i + 3]);
+    }
+    static __device__ __forceinline__ float one(const float *p) { return *p; }
+};
+template <> struct BnIO<__hip_bfloat16, 8> {
+    static __device__ __forceinline__ void load(const __hip_bfloat16 *p, float (&v)[8]) {
+        const uint4 x = *reinterpret_cast<const uint4 *>(p);
+        const unsigned w[4] = {x.x, x.y, x.z, x.w};
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            v[2 * i] = __uint_as_float(w[i] << 16);
+            v[2 * i + 1] = __uint_as_float(w[i] & 0xffff0000u);
+        }
+    }
+    static __device__ __forceinline__ void store(__hip_bfloat16 *p, const float (&v)[8]) {
+        unsigned w[4];
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const __hip_bfloat16 lo = __float2bfloat16(v[2 * i]);
+            const __hip_bfloat16 hi = __float2bfloat16(v[2 * i + 1]);
+            w[i] = (unsigned)(*reinterpret_cast<const unsigned short *>(&lo)) |
+                   ((unsigned)(*reinterpret_cast<const unsigned short *>(&hi)) << 16);
+        }
+        *reinterpret_cast<uint4 *>(p) = make_uint4(w[0], w[1], w[2], w[3]);
+    }
+    static __device__ __forceinline__ float one(const __hip_bfloat16 *p) {
+        return __uint_as_float((unsigned)(*reinterpret_cast<const unsigned short *>(p)) << 16);
+    }
+};
+template <typename T> struct BnElems { static constexpr int NE = sizeof(T) == 2 ? 8 : 4; };
+
+__device__ __forceinline__ float lrelu_f(float z, float slope) { return z > 0.0f ? z : z * slope; }
+// pre-activation, written ONCE so that forward and backward see the same sign
+__device__ __forceinline__ float bn_z(float v, float mu, float a, float beta) { return (v - mu) * a + beta; }
+
+// Column reduction of NQ quantities per channel: every thread has acc[NQ][NE] for its 16-byte
+// column chunk; threads sharing a chunk are tid, tid+cpr, ...; result -> part[(block*NQ+q)*C + c].
+template <int NQ, int NE>
+__device__ __forceinline__ void block_column_reduce(float (&acc)[NQ][NE], int cpr, int rpi, int C,
+                                                    float *__restrict__ part) {
+    __shared__ float red[BN_THREADS * NQ * NE];
+    const int tid = threadIdx.x;
+#pragma unroll
+    for (int q = 0; q < NQ; ++q)
+#pragma unroll
+        for (int i = 0; i < NE; ++i) red[(q * NE + i) * BN_THREADS + tid] = acc[q][i];
+    __syncthreads();
+    if (tid < cpr) {
+#pragma unroll
+        for (int q = 0; q < NQ; ++q)
+#pragma unroll
+            for (int i = 0; i < NE; ++i) {
+                float s = 0.0f;
+                for (int r = 0; r < rpi; ++r) s += red[(q * NE + i) * BN_THREADS + tid + r * cpr];
+                part[((size_t)blockIdx.x * NQ + q) * C + tid * NE + i] = s;
+            }
+    }
+}
+
+// ------------------------------------------------------------------ forward statistics
+template <typename T>
+__global__ __launch_bounds__(BN_THREADS) void rowbn_stats_kernel(const T *__restrict__ x, long long P, int C,
+                                                                 float *__restrict__ part) {
+    constexpr int NE = BnElems<T>::NE;
+    const int cpr = C / NE, rpi = BN_THREADS / cpr;  // chunks per row, rows per iteration
+    const int tid = threadIdx.x;
+    const int chunk = tid % cpr, rsub = tid / cpr;
+    float acc[2][NE];
+    float piv[NE];
+#pragma unroll
+    for (int i = 0; i < NE; ++i) { acc[0][i] = 0.0f; acc[1][i] = 0.0f; }
+    if (rsub < rpi) {
+        BnIO<T, NE>::load(x + chunk * NE, piv);  // pivot = first row
+        for (long long r = (long long)blockIdx.x * rpi + rsub; r < P; r += (long long)gridDim.x * rpi) {
+            float v[NE];
+            BnIO<T, NE>::load(x + r * C + chunk * NE, v);
+#pragma unroll
+            for (int i = 0; i < NE; ++i) {
+                const float d = v[i] - piv[i];
+                acc[0][i] += d;
+                acc[1][i] += d * d;
+            }
+        }
+    }
+    block_column_reduce<2, NE>(acc, cpr, rpi, C, part);
+}
+
+// Sum the per-workgroup partials of two quantities for 16 channels per workgroup: 16 lanes of
+// partial rows x 16 channels, fp64, one LDS step.  Returns true in the lane that owns channel c.
+__device__ __forceinline__ bool finalize_sums(const float *__restrict__ part, int G, int C, int &c, double &s0,
+                                              double &s1) {
+    __shared__ double red[2][16][16];
+    const int cl = threadIdx.x & 15, gl = threadIdx.x >> 4;
+    c = blockIdx.x * 16 + cl;
+    double a0 = 0.0, a1 = 0.0;
+    if (c < C)
+        for (int g = gl; g < G; g += 16) {
+            a0 += part[((size_t)g * 2 + 0) * C + c];
+            a1 += part[((size_t)g * 2 + 1) * C + c];
+        }
+    red[0][gl][cl] = a0;
+    red[1][gl][cl] = a1;
+    __syncthreads();
+    if (gl != 0 || c >= C) return false;
+    s0 = 0.0; s1 = 0.0;
+    for (int r = 0; r < 16; ++r) { s0 += red[0][r][cl]; s1 += red[1][r][cl]; }
+    return true;
+}
+
+// partials -> mean, rstd (+ running-stat update as nn.BatchNorm does); grid = ceil(C/16)
+template <typename T>
+__global__ __launch_bounds__(BN_THREADS) void rowbn_stats_finalize_kernel(
+    const T *__restrict__ x, const float *__restrict__ part, int G, long long P, int C, float eps,
+    float momentum, float *__restrict__ running_mean, float *__restrict__ running_var,
+    float *__restrict__ mean, float *__restrict__ rstd) {
+    int c;
+    double s, ss;
+    if (!finalize_sums(part, G, C, c, s, ss)) return;
+    const double piv = BnIO<T, BnElems<T>::NE>::one(x + c);
+    const double m = s / (double)P;
+    double var = ss / (double)P - m * m;  // biased, about the pivot
+    var = var < 0.0 ? 0.0 : var;
+    mean[c] = (float)(piv + m);
+    rstd[c] = (float)(1.0 / sqrt(var + (double)eps));
+    if (running_mean) {
+        const double unbiased = P > 1 ? var * (double)P / (double)(P - 1) : var;
+        running_mean[c] = (float)((1.0 - momentum) * running_mean[c] + momentum * (piv + m));
+        running_var[c] = (float)((1.0 - momentum) * running_var[c] + momentum * unbiased);
+    }
+}
+
+// ------------------------------------------------------------------ forward apply (+max)
+template <typename TI, typename TO>
+__global__ __launch_bounds__(BN_THREADS) void rowbn_apply_kernel(
+    const TI *__restrict__ x, long long P, int C, const float *__restrict__ mean,
+    const float *__restrict__ rstd, const float *__restrict__ gamma, const float *__restrict__ beta,
+    float slope, TO *__restrict__ y, unsigned total) {
+    constexpr int NE = (sizeof(TI) == 2 || sizeof(TO) == 2) ? 8 : 4;
+    const unsigned cpr = (unsigned)C / NE;
+    for (unsigned t = blockIdx.x * BN_THREADS + threadIdx.x; t < total; t += gridDim.x * BN_THREADS) {
+        const unsigned row = t / cpr, col = (t - row * cpr) * NE;
+        float v[NE];
+        BnIO<TI, NE>::load(x + (size_t)row * C + col, v);
+#pragma unroll
+        for (int i = 0; i < NE; ++i) {
+            const float a = (gamma ? gamma[col + i] : 1.0f) * rstd[col + i];
+            v[i] = lrelu_f(bn_z(v[i], mean[col + i], a, beta ? beta[col + i] : 0.0f), slope);
+        }
+        BnIO<TO, NE>::store(y + (size_t)row * C + col, v);
+    }
+}
+
+// groups of K consecutive rows -> one row (max) + arg-max byte per channel (first maximum)
+template <typename TI, typename TO>
+__global__ __launch_bounds__(BN_THREADS) void rowbn_apply_max_kernel(
+    const TI *__restrict__ x, int K, int C, const float *__restrict__ mean, const float *__restrict__ rstd,
+    const float *__restrict__ gamma, const float *__restrict__ beta, float slope, TO *__restrict__ y,
+    uint8_t *__restrict__ arg, unsigned total) {
+    constexpr int NE = (sizeof(TI) == 2 || sizeof(TO) == 2) ? 8 : 4;
+    const unsigned cpr = (unsigned)C / NE;
+    for (unsigned t = blockIdx.x * BN_THREADS + threadIdx.x; t < total; t += gridDim.x * BN_THREADS) {
+        const unsigned grp = t / cpr, col = (t - grp * cpr) * NE;
+        float a[NE], b[NE], mu[NE], best[NE];
+        int bk[NE];
+#pragma unroll
+        for (int i = 0; i < NE; ++i) {
+            a[i] = (gamma ? gamma[col + i] : 1.0f) * rstd[col + i];
+            b[i] = beta ? beta[col + i] : 0.0f;
+            mu[i] = mean[col + i];
+            best[i] = -INFINITY;
+            bk[i] = 0;
+        }
+        for (int k = 0; k < K; ++k) {
+            float v[NE];
+            BnIO<TI, NE>::load(x + ((size_t)grp * K + k) * C + col, v);
+#pragma unroll
+            for (int i = 0; i < NE; ++i) {
+                const float z = lrelu_f(bn_z(v[i], mu[i], a[i], b[i]), slope);
+                if (z > best[i]) { best[i] = z; bk[i] = k; }
+            }
+        }
+        BnIO<TO, NE>::store(y + (size_t)grp * C + col, best);
+#pragma unroll
+        for (int i = 0; i < NE; ++i) arg[(size_t)grp * C + col + i] = (uint8_t)bk[i];
+    }
+}
+
+// ------------------------------------------------------------------ backward reductions
+// part[(block*2+0)*C + c] = sum g, part[(block*2+1)*C + c] = sum g*xhat
+template <typename TI, typename TG>
+__global__ __launch_bounds__(BN_THREADS) void rowbn_bwd_reduce_kernel(
+    const TG *__restrict__ gy, const TI *__restrict__ x, long long P, int C, const float *__restrict__ mean,
+    const float *__restrict__ rstd, const float *__restrict__ gamma, const float *__restrict__ beta,
+    float slope, float *__restrict__ part) {
+    constexpr int NE = (sizeof(TI) == 2 || sizeof(TG) == 2) ? 8 : 4;
+    const int cpr = C / NE, rpi = BN_THREADS / cpr;
+    const int tid = threadIdx.x;
+    const int chunk = tid % cpr, rsub = tid / cpr;
+    float acc[2][NE], a[NE], b[NE], mu[NE], rs[NE];
+#pragma unroll
+    for (int i = 0; i < NE; ++i) {
+        acc[0][i] = 0.0f; acc[1][i] = 0.0f;
+        const int c = chunk * NE + i;
+        mu[i] = mean[c]; rs[i] = rstd[c];
+        a[i] = (gamma ? gamma[c] : 1.0f) * rs[i];
+        b[i] = beta ? beta[c] : 0.0f;
+    }
+    if (rsub < rpi) {
+        for (long long r = (long long)blockIdx.x * rpi + rsub; r < P; r += (long long)gridDim.x * rpi) {
+            float v[NE], g[NE];
+            BnIO<TI, NE>::load(x + r * C + chunk * NE, v);
+            BnIO<TG, NE>::load(gy + r * C + chunk * NE, g);
+#pragma unroll
+            for (int i = 0; i < NE; ++i) {
+                const float gg = bn_z(v[i], mu[i], a[i], b[i]) > 0.0f ? g[i] : g[i] * slope;
+                acc[0][i] += gg;
+                acc[1][i] += gg * ((v[i] - mu[i]) * rs[i]);
+            }
+        }
+    }
+    block_column_reduce<2, NE>(acc, cpr, rpi, C, part);
+}
+
+// max variant: gy is (P/K, C); only the arg-max row of each group carries gradient
+template <typename TI, typename TG>
+__global__ __launch_bounds__(BN_THREADS) void rowbn_bwd_reduce_max_kernel(
+    const TG *__restrict__ gy, const TI *__restrict__ x, const uint8_t *__restrict__ arg, long long Gp,
+    int K, int C, const float *__restrict__ mean, const float *__restrict__ rstd,
+    const float *__restrict__ gamma, const float *__restrict__ beta, float slope, float *__restrict__ part) {
+    constexpr int NE = (sizeof(TI) == 2 || sizeof(TG) == 2) ? 8 : 4;
+    const int cpr = C / NE, rpi = BN_THREADS / cpr;
+    const int tid = threadIdx.x;
+    const int chunk = tid % cpr, rsub = tid / cpr;
+    float acc[2][NE], a[NE], b[NE], mu[NE], rs[NE];
+#pragma unroll
+    for (int i = 0; i < NE; ++i) {
+        acc[0][i] = 0.0f; acc[1][i] = 0.0f;
+        const int c = chunk * NE + i;
+        mu[i] = mean[c]; rs[i] = rstd[c];
+        a[i] = (gamma ? gamma[c] : 1.0f) * rs[i];
+        b[i] = beta ? beta[c] : 0.0f;
+    }
+    if (rsub < rpi) {
+        for (long long r = (long long)blockIdx.x * rpi + rsub; r < Gp; r += (long long)gridDim.x * rpi) {
+            float g[NE];
+            BnIO<TG, NE>::load(gy + r * C + chunk * NE, g);
+#pragma unroll
+            for (int i = 0; i < NE; ++i) {
+                const int c = chunk * NE + i;
+                const int k = arg[r * C + c];
+                const float v = BnIO<TI, NE>::one(x + (r * K + k) * C + c);
+                const float gg = bn_z(v, mu[i], a[i], b[i]) > 0.0f ? g[i] : g[i] * slope;
+                acc[0][i] += gg;
+                acc[1][i] += gg * ((v - mu[i]) * rs[i]);
+            }
+        }
+    }
+    block_column_reduce<2, NE>(acc, cpr, rpi, C, part);
+}
+
+// partials -> dgamma, dbeta (fp32) and the two per-channel constants of dx; grid = ceil(C/16)
+__global__ __launch_bounds__(BN_THREADS) void rowbn_bwd_finalize_kernel(const float *__restrict__ part, int G,
+                                                                        long long P, int C, int training,
+                                                                        float *__restrict__ dgamma,
+                                                                        float *__restrict__ dbeta,
+                                                                        float *__restrict__ c12) {
+    int c;
+    double s, sx;
+    if (!finalize_sums(part, G, C, c, s, sx)) return;
+    if (dbeta) dbeta[c] = (float)s;
+    if (dgamma) dgamma[c] = (float)sx;
+    c12[c] = training ? (float)(s / (double)P) : 0.0f;       // eval-mode BN: no batch terms
+    c12[C + c] = training ? (float)(sx / (double)P) : 0.0f;
+}
+
+// dx = a * (g - c1 - xhat*c2); K > 0: g lives only on each group's arg-max row
+template <typename TI, typename TG>
+__global__ __launch_bounds__(BN_THREADS) void rowbn_bwd_apply_kernel(
+    const TG *__restrict__ gy, const TI *__restrict__ x, const uint8_t *__restrict__ arg, int K, int C,
+    const float *__restrict__ mean, const float *__restrict__ rstd, const float *__restrict__ gamma,
+    const float *__restrict__ beta, float slope, const float *__restrict__ c12, TI *__restrict__ dx,
+    unsigned total) {
+    constexpr int NE = (sizeof(TI) == 2 || sizeof(TG) == 2) ? 8 : 4;
+    const unsigned cpr = (unsigned)C / NE;
+    for (unsigned t = blockIdx.x * BN_THREADS + threadIdx.x; t < total; t += gridDim.x * BN_THREADS) {
+        const unsigned row = t / cpr, col = (t - row * cpr) * NE;
+        float v[NE], g[NE];
+        BnIO<TI, NE>::load(x + (size_t)row * C + col, v);
+        unsigned k = 0;
+        size_t grow = row;
+        if (K > 0) { grow = row / (unsigned)K; k = row - (unsigned)grow * K; }
+        BnIO<TG, NE>::load(gy + grow * C + col, g);
+#pragma unroll
+        for (int i = 0; i < NE; ++i) {
+            const int c = col + i;
+            const float rs = rstd[c], mu = mean[c];
+            const float a = (gamma ? gamma[c] : 1.0f) * rs;
+            float gg = bn_z(v[i], mu, a, beta ? beta[c] : 0.0f) > 0.0f ? g[i] : g[i] * slope;
+            if (K > 0 && arg[grow * C + c] != k) gg = 0.0f;
+            v[i] = a * (gg - c12[c] - (v[i] - mu) * rs * c12[C + c]);
+        }
+        BnIO<TI, NE>::store(dx + (size_t)row * C + col, v);
+    }
+}
+
+int stats_blocks(long long rows, int rpi) {
+    long long b = (rows + (long long)rpi * 8 - 1) / ((long long)rpi * 8);  // >= 8 rows per thread
+    return (int)(b < 1 ? 1 : (b > BN_MAX_BLOCKS ? BN_MAX_BLOCKS : b));
+}
+unsigned ew_blocks(unsigned total) {
+    const unsigned b = (total + BN_THREADS - 1) / BN_THREADS;
+    return b < 1u ? 1u : (b > 16384u ? 16384u : b);
+}
+bool bn_shape_ok(int dtype_a, int dtype_b, int C) {
+    const int ne = (dtype_a == TPG_DTYPE_BF16 || dtype_b == TPG_DTYPE_BF16) ? 8 : 4;
+    return C > 0 && C % ne == 0 && C / 4 <= BN_THREADS;   // <= 1024 channels (column-sum layout)
+}
+bool bn_dtype_ok(int d) { return d == TPG_DTYPE_F32 || d == TPG_DTYPE_BF16; }
+
+}  // namespace
+
+extern "C" size_t tpg_rowbn_workspace_bytes(int C) {
+    return sizeof(float) * ((size_t)BN_MAX_BLOCKS * 2 * C + 2 * (size_t)C);
+}
+
+extern "C" int tpg_rowbn_fwd(const void *x, int dtype_in, long long P, int K, int C, float eps, float momentum,
+                             int training, float *running_mean, float *running_var, const float *gamma,
+                             const float *beta, float slope, float *mean, float *rstd, void *y, int dtype_out,
+                             uint8_t *argmax, void *ws, void *stream) {
+    if (P <= 0 || C <= 0 || K < 0 || K > 256 || (K > 0 && P % K)) return TPG_ERR_ARG;
+    if (!x || !mean || !rstd || !y || !ws || (K > 0 && !argmax)) return TPG_ERR_ARG;
+    if (!bn_dtype_ok(dtype_in) || !bn_dtype_ok(dtype_out) || !bn_shape_ok(dtype_in, dtype_out, C))
+        return TPG_ERR_UNSUPPORTED;
+    if ((reinterpret_cast<uintptr_t>(x) | reinterpret_cast<uintptr_t>(y)) & 15) return TPG_ERR_UNSUPPORTED;
+    hipStream_t st = tpg_stream(stream);
+    float *part = static_cast<float *>(ws);
+    if (training) {
+        // statistics use the INPUT type's vector width
+        const int ne = dtype_in == TPG_DTYPE_BF16 ? 8 : 4;
+        const int rpi = BN_THREADS / (C / ne);
+        const int G = stats_blocks(P, rpi);
+        if (dtype_in == TPG_DTYPE_BF16) {
+            const __hip_bfloat16 *xx = static_cast<const __hip_bfloat16 *>(x);
+            hipLaunchKernelGGL(rowbn_stats_kernel<__hip_bfloat16>, dim3(G), dim3(BN_THREADS), 0, st, xx, P, C, part);
+            hipLaunchKernelGGL(rowbn_stats_finalize_kernel<__hip_bfloat16>, dim3((C + 15) / 16), dim3(BN_THREADS), 0, st, xx,
+                               part, G, P, C, eps, momentum, running_mean, running_var, mean, rstd);
+        } else {
+            const float *xx = static_cast<const float *>(x);
+            hipLaunchKernelGGL(rowbn_stats_kernel<float>, dim3(G), dim3(BN_THREADS), 0, st, xx, P, C, part);
+            hipLaunchKernelGGL(rowbn_stats_finalize_kernel<float>, dim3((C + 15) / 16), dim3(BN_THREADS), 0, st, xx, part, G,
+                               P, C, eps, momentum, running_mean, running_var, mean, rstd);
+        }
+    }  // eval mode: the caller has filled mean / rstd from the running statistics
+    const int ne = (dtype_in == TPG_DTYPE_BF16 || dtype_out == TPG_DTYPE_BF16) ? 8 : 4;
+    const long long rows_out = K > 0 ? P / K : P;
+    const unsigned long long total64 = (unsigned long long)rows_out * (C / ne);
+    if (total64 >= 0x7fffffffULL) return TPG_ERR_ARG;
+    const unsigned total = (unsigned)total64;
+    const dim3 g(ew_blocks(total)), blk(BN_THREADS);
+#define TPG_BN_APPLY(TI, TO)                                                                              \
+    do {                                                                                                  \
+        if (K > 0)                                                                                        \
+            hipLaunchKernelGGL((rowbn_apply_max_kernel<TI, TO>), g, blk, 0, st, static_cast<const TI *>(x), K, C, \
+                               mean, rstd, gamma, beta, slope, static_cast<TO *>(y), argmax, total);      \
+        else                                                                                              \
+            hipLaunchKernelGGL((rowbn_apply_kernel<TI, TO>), g, blk, 0, st, static_cast<const TI *>(x), P, C, mean, \
+                               rstd, gamma, beta, slope, static_cast<TO *>(y), total);                    \
+    } while (0)
+    if (dtype_in == TPG_DTYPE_F32 && dtype_out == TPG_DTYPE_F32) TPG_BN_APPLY(float, float);
+    else if (dtype_in == TPG_DTYPE_F32) TPG_BN_APPLY(float, __hip_bfloat16);
+    else if (dtype_out == TPG_DTYPE_F32) TPG_BN_APPLY(__hip_bfloat16, float);
+    else TPG_BN_APPLY(__hip_bfloat16, __hip_bfloat16);
+#undef TPG_BN_APPLY
+    TPG_RETURN_IF_LAUNCH_FAILED();
+    return TPG_OK;
+}
+
+extern "C" int tpg_rowbn_bwd(const void *gy, int dtype_g, const void *x, int dtype_in, const uint8_t *argmax,
+                             long long P, int K, int C, int training, const float *mean, const float *rstd,
+                             const float *gamma, const float *beta, float slope, float *dgamma, float *dbeta,
+                             void *dx, void *ws, void *stream) {
+    if (P <= 0 || C <= 0 || K < 0 || K > 256 || (K > 0 && P % K)) return TPG_ERR_ARG;
+    if (!gy || !x || !mean || !rstd || !dx || !ws || (K > 0 && !argmax)) return TPG_ERR_ARG;
+    if (!bn_dtype_ok(dtype_in) || !bn_dtype_ok(dtype_g) || !bn_shape_ok(dtype_in, dtype_g, C))
+        return TPG_ERR_UNSUPPORTED;
+    if ((reinterpret_cast<uintptr_t>(x) | reinterpret_cast<uintptr_t>(gy) | reinterpret_cast<uintptr_t>(dx)) & 15)
+        return TPG_ERR_UNSUPPORTED;
+    hipStream_t st = tpg_stream(stream);
+    float *part = static_cast<float *>(ws);
+    float *c12 = part + (size_t)BN_MAX_BLOCKS * 2 * C;
+    const int ne = (dtype_in == TPG_DTYPE_BF16 || dtype_g == TPG_DTYPE_BF16) ? 8 : 4;
+    const int rpi = BN_THREADS / (C / ne);
+    const long long rows_g = K > 0 ? P / K : P;
+    const int G = stats_blocks(rows_g, rpi);
+    const unsigned long long total64 = (unsigned long long)P * (C / ne);
+    if (total64 >= 0x7fffffffULL) return TPG_ERR_ARG;
+    const unsigned total = (unsigned)total64;
+#define TPG_BN_BWD(TI, TG)                                                                                  \
+    do {                                                                                                    \
+        const TI *xx = static_cast<const TI *>(x);                                                          \
+        const TG *gg = static_cast<const TG *>(gy);                                                         \
+        if (K > 0)                                                                                          \
+            hipLaunchKernelGGL((rowbn_bwd_reduce_max_kernel<TI, TG>), dim3(G), dim3(BN_THREADS), 0, st, gg, xx, \
+                               argmax, rows_g, K, C, mean, rstd, gamma, beta, slope, part);                 \
+        else                                                                                                \
+            hipLaunchKernelGGL((rowbn_bwd_reduce_kernel<TI, TG>), dim3(G), dim3(BN_THREADS), 0, st, gg, xx, P, C, \
+                               mean, rstd, gamma, beta, slope, part);                                       \
+        hipLaunchKernelGGL(rowbn_bwd_finalize_kernel, dim3((C + 15) / 16), dim3(BN_THREADS), 0, st, part, G, P, C, training, \
+                           dgamma, dbeta, c12);                                                             \
+        hipLaunchKernelGGL((rowbn_bwd_apply_kernel<TI, TG>), dim3(ew_blocks(total)), dim3(BN_THREADS), 0, st, gg, \
+                           xx, argmax, K, C, mean, rstd, gamma, beta, slope, c12, static_cast<TI *>(dx), total); \
+    } while (0)
+    if (dtype_in == TPG_DTYPE_F32 && dtype_g == TPG_DTYPE_F32) TPG_BN_BWD(float, float);
+    else if (dtype_in == TPG_DTYPE_F32) TPG_BN_BWD(float, __hip_bfloat16);
+    else if (dtype_g == TPG_DTYPE_F32) TPG_BN_BWD(__hip_bfloat16, float);
+    else TPG_BN_BWD(__hip_bfloat16, __hip_bfloat16);
+#undef TPG_BN_BWD
+    TPG_RETURN_IF_LAUNCH_FAILED();
+    return TPG_OK;
+}

@@ -256,6 +256,39 @@ class HipBackend:
         return gU, gQE
 
 
+    # ---- fused BatchNorm + LeakyReLU (+ max over K) on rows (csrc/rowbn.hip) -------------
+    def _bn_ws(self, x, C_):
+        n = self.lib.tpg_rowbn_workspace_bytes(C_)
+        return torch.empty(n // 4, dtype=torch.float32, device=x.device)
+
+    def rowbn_fwd(self, x, K, eps, momentum, training, running_mean, running_var, gamma, beta, slope,
+                  mean, rstd, out_dtype):
+        P, Cc = x.shape
+        rows = P // K if K else P
+        y = torch.empty((rows, Cc), dtype=out_dtype, device=x.device)
+        arg = torch.empty((rows, Cc), dtype=torch.uint8, device=x.device) if K else None
+        ws = self._bn_ws(x, Cc)
+        nbytes = x.element_size() * P * Cc * (2 if training else 1) + y.element_size() * rows * Cc
+        self._call("tpg_rowbn_fwd", "rowbn_fwd", nbytes, x,
+                   _ptr(x), _DTYPE_CODE[x.dtype], P, K, Cc, float(eps), float(momentum), int(training),
+                   _ptr(running_mean), _ptr(running_var), _ptr(gamma), _ptr(beta), float(slope), _ptr(mean),
+                   _ptr(rstd), _ptr(y), _DTYPE_CODE[out_dtype], _ptr(arg), _ptr(ws))
+        return y, arg
+
+    def rowbn_bwd(self, gy, x, arg, K, training, mean, rstd, gamma, beta, slope, need_affine):
+        P, Cc = x.shape
+        dx = torch.empty_like(x)
+        dgamma = torch.empty(Cc, dtype=torch.float32, device=x.device) if need_affine else None
+        dbeta = torch.empty(Cc, dtype=torch.float32, device=x.device) if need_affine else None
+        ws = self._bn_ws(x, Cc)
+        nbytes = 2 * gy.element_size() * gy.numel() + x.element_size() * P * Cc * 3
+        self._call("tpg_rowbn_bwd", "rowbn_bwd", nbytes, x,
+                   _ptr(gy), _DTYPE_CODE[gy.dtype], _ptr(x), _DTYPE_CODE[x.dtype], _ptr(arg), P, K, Cc,
+                   int(training), _ptr(mean), _ptr(rstd), _ptr(gamma), _ptr(beta), float(slope), _ptr(dgamma),
+                   _ptr(dbeta), _ptr(dx), _ptr(ws))
+        return dx, dgamma, dbeta
+
+
 _DTYPE_CODE = {torch.float32: 0, torch.bfloat16: 1}
 _hip = None
 
@@ -525,3 +558,53 @@ def row_combine(U, QE, idx, mode, slope=0.2, out_dtype=None):
     ne = 4 if (U.dtype == torch.float32 and out_dtype == torch.float32) else 8
     _need(U.shape[2] % ne == 0, f"channel count {U.shape[2]} must be a multiple of {ne}")
     return _RowCombine.apply(U, QE, idx, mode, float(slope), out_dtype)
+
+
+# ------------------------------------------------ fused BatchNorm + LeakyReLU (+ max over K)
+class _RowBNAct(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x, gamma, beta, running_mean, running_var, training, momentum, eps, slope, K, out_dtype):
+        be = backend_for(x)
+        C_ = x.shape[1]
+        if training:
+            mean = torch.empty(C_, dtype=torch.float32, device=x.device)
+            rstd = torch.empty(C_, dtype=torch.float32, device=x.device)
+        else:
+            mean = running_mean.float().contiguous()
+            rstd = torch.rsqrt(running_var.float() + eps)
+        y, arg = be.rowbn_fwd(x, K, eps, momentum, training, running_mean if training else None,
+                              running_var if training else None, gamma, beta, slope, mean, rstd, out_dtype)
+        ctx.save_for_backward(x, gamma, beta, mean, rstd, arg)
+        ctx.cfg = (training, slope, K)
+        return y
+
+    @staticmethod
+    def backward(ctx, gy):
+        x, gamma, beta, mean, rstd, arg = ctx.saved_tensors
+        training, slope, K = ctx.cfg
+        gy = gy.contiguous()
+        if gy.dtype not in _DTYPE_CODE:
+            gy = gy.float()
+        need_affine = gamma is not None and (ctx.needs_input_grad[1] or ctx.needs_input_grad[2])
+        dx, dgamma, dbeta = backend_for(x).rowbn_bwd(gy, x, arg, K, training, mean, rstd, gamma, beta, slope,
+                                                    need_affine)
+        return dx, dgamma, dbeta, None, None, None, None, None, None, None, None
+
+
+def row_bn_act(x, gamma, beta, running_mean, running_var, training, momentum, eps, slope=1.0, K=0,
+               out_dtype=None):
+    """Fused BatchNorm (+LeakyReLU, + max over groups of K rows) on rows (include/tpgan_ops.h).
+
+    x (P,C) fp32/bf16 -> (P,C) or (P/K,C).  slope: 1.0 = no activation, 0.0 = ReLU.  In training mode
+    the running statistics are updated in place (momentum, unbiased variance) like nn.BatchNorm."""
+    _need(x.dim() == 2 and x.dtype in _DTYPE_CODE, "x must be (P,C) fp32/bf16")
+    _need(K == 0 or (0 < K <= 256 and x.shape[0] % K == 0), "K must divide the row count (<= 256)")
+    out_dtype = out_dtype or x.dtype
+    ne = 4 if (x.dtype == torch.float32 and out_dtype == torch.float32) else 8
+    _need(x.shape[1] % ne == 0 and x.shape[1] <= 1024, f"channels must be a multiple of {ne}, <= 1024")
+    if not training:
+        _need(running_mean is not None and running_var is not None, "eval mode needs running statistics")
+    g = None if gamma is None else gamma.float().contiguous()
+    b = None if beta is None else beta.float().contiguous()
+    return _RowBNAct.apply(x.contiguous(), g, b, running_mean, running_var, bool(training), float(momentum),
+                           float(eps), float(slope), int(K), out_dtype)

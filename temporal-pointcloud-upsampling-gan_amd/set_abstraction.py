@@ -71,8 +71,12 @@ def conv_weight2d(conv):
     """(Cout,Cin) weight of a 1x1 conv AS THE MODULE CALL WOULD SEE IT: runs the module's
     forward pre-hooks (old-style spectral norm: one power iteration in training mode and
     `weight = weight_orig / sigma`, exactly once per forward as in the reference)."""
-    for hook in conv._forward_pre_hooks.values():
-        hook(conv, ())
+    # the power iteration always runs in fp32: under bf16 autocast its mat-vec would be cast
+    # to bf16 (worse sigma estimate, and a 2.3 ms host-side rocBLAS bf16 gemv per call)
+    with torch.autocast(device_type=conv.weight_orig.device.type if hasattr(conv, "weight_orig")
+                        else conv.weight.device.type, enabled=False):
+        for hook in conv._forward_pre_hooks.values():
+            hook(conv, ())
     return conv.weight.view(conv.weight.shape[0], -1)
 
 
@@ -94,16 +98,64 @@ def bn_rows(bn, x):
     return y.view(shape)
 
 
-def mlp_tail_rows(layers, x):
-    """Run [conv, (bn), act]* layers (from a given position) on rows."""
-    for m in layers:
+def _act_slope(m):
+    """LeakyReLU slope of an activation module (ReLU = 0), or None if it is something else."""
+    if isinstance(m, nn.ReLU):
+        return 0.0
+    if isinstance(m, nn.LeakyReLU):
+        return float(m.negative_slope)
+    return None
+
+
+def _fusable(x, K):
+    C = x.shape[-1]
+    return x.dtype in (torch.float32, torch.bfloat16) and C % 8 == 0 and C <= 1024 and K <= 256
+
+
+def bn_act_rows(bn, x, slope, K=0):
+    """Fused BatchNorm + LeakyReLU(slope) [+ max over each group of K rows] on rows (P,C)
+    (ops.row_bn_act, csrc/rowbn.hip); module state handled like nn.BatchNorm's own forward."""
+    training = bn.training or (bn.running_mean is None and bn.running_var is None)
+    momentum = 0.0 if bn.momentum is None else bn.momentum
+    if bn.training and bn.track_running_stats and bn.num_batches_tracked is not None:
+        bn.num_batches_tracked.add_(1)
+        if bn.momentum is None:
+            momentum = 1.0 / float(bn.num_batches_tracked)
+    track = bn.track_running_stats and bn.running_mean is not None
+    return ops.row_bn_act(x, bn.weight, bn.bias, bn.running_mean if track else None,
+                          bn.running_var if track else None, training, momentum, bn.eps, slope, K,
+                          out_dtype=amp_dtype(x))
+
+
+def mlp_tail_rows(layers, x, reduce_max=False):
+    """Run [conv, (bn), act]* layers (from a given position) on rows x (...,K,C).
+
+    BatchNorm + activation pairs go through the fused kernel; with `reduce_max` the max over
+    the second-to-last axis (the K neighbours) is fused into the final pair."""
+    lead, K = x.shape[:-2], x.shape[-2]
+    x = x.reshape(-1, x.shape[-1])
+    i, n, reduced = 0, len(layers), False
+    while i < n:
+        m = layers[i]
         if isinstance(m, nn.Conv2d):
             x = F.linear(x, conv_weight2d(m), m.bias)
         elif isinstance(m, (nn.BatchNorm2d, nn.BatchNorm1d)):
-            x = bn_rows(m, x)
+            slope = _act_slope(layers[i + 1]) if i + 1 < n else None
+            last = reduce_max and not any(isinstance(l, nn.Conv2d) for l in layers[i + 1:])
+            if slope is not None and _fusable(x, K if last else 0):
+                x = bn_act_rows(m, x, slope, K if last else 0)
+                reduced = reduced or last
+                i += 1                                             # the activation is consumed
+            else:
+                x = bn_rows(m, x)
         else:
             x = m(x)
-    return x
+        i += 1
+    if reduce_max:
+        if not reduced:
+            x = x.view(-1, K, x.shape[-1]).max(dim=1)[0]
+        return x.view(*lead, x.shape[-1])
+    return x.view(*lead, K, x.shape[-1])
 
 
 class QueryAndGroup(nn.Module):
@@ -207,8 +259,7 @@ class _PointnetSAModuleBase(nn.Module):
         for grouper, mlp in zip(self.groupers, self.mlps):
             if rows_first():
                 y = self._first_layer(grouper, mlp, xyz, new_xyz, feat_rows)
-                y = mlp_tail_rows(list(mlp)[1:], y)                # (B,S,ns,C')
-                outs.append(y.max(dim=2)[0])
+                outs.append(mlp_tail_rows(list(mlp)[1:], y, reduce_max=True))   # (B,S,C')
             else:                                                  # discriminator.py:139-150
                 planes = None if feat_rows is None else feat_rows.float().transpose(1, 2).contiguous()
                 g = mlp(grouper(xyz, new_xyz, planes))             # (B,C',S,ns)
@@ -246,7 +297,7 @@ class _PointnetSAModuleBase(nn.Module):
                 Qs.append(F.linear(new_xyz[sl], W[:, :3]))
         y = ops.row_combine(torch.cat(Us, 0), torch.cat(Qs, 0), idx, ops.ROW_SUB, out_dtype=amp_dtype(xyz))
         tail = list(mlp)[1:]
-        feats = [mlp_tail_rows(tail, y[t * B:(t + 1) * B]).max(dim=2)[0] for t in range(T)]
+        feats = [mlp_tail_rows(tail, y[t * B:(t + 1) * B], reduce_max=True) for t in range(T)]
         return [new_xyz[t * B:(t + 1) * B] for t in range(T)], feats
 
     def forward(self, xyz, features):
@@ -323,10 +374,20 @@ class FlowEmbedding(nn.Module):
             U = F.linear(torch.cat([p2.float(), f2.float()], dim=-1), W[:, :3 + C])
             Q = F.linear(p1.float(), W[:, :3]) - F.linear(f1.float(), W[:, 3 + C:])
         x = ops.row_combine(U, Q, idx, ops.ROW_SUB, out_dtype=amp_dtype(p1))     # (B,N,32,C1)
-        x = F.leaky_relu(bn_rows(self.mlp_bns[0], x))
-        for conv, bn in zip(list(self.mlp_convs)[1:], list(self.mlp_bns)[1:]):
-            x = F.leaky_relu(bn_rows(bn, F.linear(x, conv_weight2d(conv))))
-        return x.max(dim=2)[0]
+        B, N, K, _ = x.shape
+        x = x.view(B * N * K, -1)
+        nl = len(self.mlp_convs)
+        for l in range(nl):                                        # F.leaky_relu default slope 0.01
+            if l:
+                x = F.linear(x, conv_weight2d(self.mlp_convs[l]))
+            last = l == nl - 1
+            if _fusable(x, K if last else 0):
+                x = bn_act_rows(self.mlp_bns[l], x, 0.01, K if last else 0)
+            else:
+                x = F.leaky_relu(bn_rows(self.mlp_bns[l], x))
+                if last:
+                    x = x.view(B * N, K, -1).max(dim=1)[0]
+        return x.view(B, N, -1)
 
     def forward(self, pos1, pos2, feature1, feature2, radius):
         """Reference signature: pos (B,3,N), feature (B,C,N) -> pos1, (B,mlp[-1],N)."""
@@ -382,6 +443,13 @@ def _head(dims, drops):
     return nn.Sequential(*layers)
 
 
+def _head_fp32(fc_layers, x):
+    """The (B,C) classification head always runs in fp32 (B rows: nothing to gain from bf16,
+    and its spectral-norm hooks fire inside the module call)."""
+    with no_autocast(x):
+        return fc_layers(x.float())
+
+
 class _TempoDis(nn.Module):
     """Per-frame SA x2 -> FlowModule over the T frames -> GroupAll SA -> FC head."""
 
@@ -399,7 +467,7 @@ class _TempoDis(nn.Module):
         feats, poss = self._levels(pos_lst, feat_lst)               # rows all the way
         f = self.flow_module.forward_rows(feats, poss, self.flow_radius_scale * cutoff)
         _, f = self.SA_pooling.forward_rows(poss[0], f)
-        return self.fc_layers(f.reshape(-1, width))
+        return _head_fp32(self.fc_layers, f.reshape(-1, width))
 
 
 class ActionTempoDis(_TempoDis):
@@ -440,7 +508,7 @@ class _SpatialDis(nn.Module):
         for sa in self.coarse_graining_module:
             pos, feature = sa.forward_rows(pos, pos if feature is None else feature)
         _, feature = self.SA_pooling.forward_rows(pos, feature)
-        return self.fc_layers(feature.reshape(-1, width))
+        return _head_fp32(self.fc_layers, feature.reshape(-1, width))
 
 
 class ActionSpatialDis(_SpatialDis):

