@@ -195,33 +195,41 @@ def rowcombine_bwd(gout, idx, E, mode, N, slope=0.2):
 # build's own fused form of [BatchNorm2d -> (Leaky)ReLU -> max over nsample]
 # (reference discriminator.py:63-78,145-150,279-282); equality with the reference is pinned at
 # model level by tests/golden.
+def _bn_preact32(x, mean, rstd, gamma, beta):
+    """z = (x - mean) * (gamma * rstd) + beta in fp32, op for op as csrc/rowbn.hip::bn_z, so the
+    sign of z (the LeakyReLU mask) is the one the kernel sees."""
+    x32 = np.asarray(x, np.float32)
+    Cc = x32.shape[1]
+    g = np.ones(Cc, np.float32) if gamma is None else np.asarray(gamma, np.float32)
+    b = np.zeros(Cc, np.float32) if beta is None else np.asarray(beta, np.float32)
+    a = g * np.asarray(rstd, np.float32)
+    return (x32 - np.asarray(mean, np.float32)) * a + b
+
+
 def rowbn_fwd(x, K, eps, gamma, beta, slope, training=True, mean=None, rstd=None):
     x64 = np.asarray(x, np.float64)
     P, Cc = x64.shape
     if training:
         mean = x64.mean(0)
-        var = x64.var(0)
-        rstd = 1.0 / np.sqrt(var + eps)
-    g = np.ones(Cc) if gamma is None else np.asarray(gamma, np.float64)
-    b = np.zeros(Cc) if beta is None else np.asarray(beta, np.float64)
-    z = (x64 - mean) * (g * rstd) + b
-    y = np.where(z > 0, z, z * slope)
+        rstd = 1.0 / np.sqrt(x64.var(0) + eps)
+    mean, rstd = np.asarray(mean, np.float32), np.asarray(rstd, np.float32)
+    z = _bn_preact32(x, mean, rstd, gamma, beta)
+    y = np.where(z > 0, z, z * np.float32(slope))
     arg = None
     if K:
         yk = y.reshape(P // K, K, Cc)
         arg = yk.argmax(1).astype(np.uint8)          # first maximum
         y = yk.max(1)
-    return y.astype(np.float32), np.asarray(mean, np.float32), np.asarray(rstd, np.float32), arg
+    return y.astype(np.float32), mean, rstd, arg
 
 
 def rowbn_bwd(gy, x, arg, K, training, mean, rstd, gamma, beta, slope):
     x64 = np.asarray(x, np.float64)
     P, Cc = x64.shape
     g_ = np.ones(Cc) if gamma is None else np.asarray(gamma, np.float64)
-    b_ = np.zeros(Cc) if beta is None else np.asarray(beta, np.float64)
+    z = _bn_preact32(x, mean, rstd, gamma, beta)
     mean, rstd = np.asarray(mean, np.float64), np.asarray(rstd, np.float64)
     xhat = (x64 - mean) * rstd
-    z = xhat * g_ + b_
     gy64 = np.asarray(gy, np.float64)
     if K:
         full = np.zeros((P // K, K, Cc))

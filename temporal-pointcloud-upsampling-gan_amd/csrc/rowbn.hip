@@ -75,8 +75,12 @@ __device__ __forceinline__ float lrelu_f(float z, float slope) { return z > 0.0f
 // pre-activation, written ONCE so that forward and backward see the same sign
 __device__ __forceinline__ float bn_z(float v, float mu, float a, float beta) { return (v - mu) * a + beta; }
 
-// Column reduction of NQ quantities per channel: every thread has acc[NQ][NE] for its 16-byte
-// column chunk; threads sharing a chunk are tid, tid+cpr, ...; result -> part[(block*NQ+q)*C + c].
+// Thread layout shared by every kernel here: a thread owns ONE 16-byte column chunk
+// (chunk = tid % cpr) and walks rows rsub, rsub + rpi, ... (rsub = tid / cpr, rpi = 256 / cpr rows
+// per workgroup iteration), so per-channel constants are loaded once and stay in registers.
+//
+// Column reduction of NQ quantities per channel: every thread has acc[NQ][NE] for its chunk;
+// all 256 threads take part: output o = (q, i, chunk) sums its rpi partners from LDS.
 template <int NQ, int NE>
 __device__ __forceinline__ void block_column_reduce(float (&acc)[NQ][NE], int cpr, int rpi, int C,
                                                     float *__restrict__ part) {
@@ -87,17 +91,18 @@ __device__ __forceinline__ void block_column_reduce(float (&acc)[NQ][NE], int cp
 #pragma unroll
         for (int i = 0; i < NE; ++i) red[(q * NE + i) * BN_THREADS + tid] = acc[q][i];
     __syncthreads();
-    if (tid < cpr) {
-#pragma unroll
-        for (int q = 0; q < NQ; ++q)
-#pragma unroll
-            for (int i = 0; i < NE; ++i) {
-                float s = 0.0f;
-                for (int r = 0; r < rpi; ++r) s += red[(q * NE + i) * BN_THREADS + tid + r * cpr];
-                part[((size_t)blockIdx.x * NQ + q) * C + tid * NE + i] = s;
-            }
+    const int nout = NQ * NE * cpr;
+    for (int o = tid; o < nout; o += BN_THREADS) {
+        const int qi = o / cpr, chunk = o - qi * cpr;   // qi = q * NE + i
+        const float *src = red + qi * BN_THREADS + chunk;
+        float s = 0.0f;
+        for (int r = 0; r < rpi; ++r) s += src[r * cpr];
+        const int q = qi / NE, i = qi - q * NE;
+        part[((size_t)blockIdx.x * NQ + q) * C + chunk * NE + i] = s;
     }
 }
+
+constexpr int BN_UNROLL = 4;  // independent 16-byte loads in flight per thread
 
 // ------------------------------------------------------------------ forward statistics
 template <typename T>
@@ -113,7 +118,22 @@ __global__ __launch_bounds__(BN_THREADS) void rowbn_stats_kernel(const T *__rest
     for (int i = 0; i < NE; ++i) { acc[0][i] = 0.0f; acc[1][i] = 0.0f; }
     if (rsub < rpi) {
         BnIO<T, NE>::load(x + chunk * NE, piv);  // pivot = first row
-        for (long long r = (long long)blockIdx.x * rpi + rsub; r < P; r += (long long)gridDim.x * rpi) {
+        const long long step = (long long)gridDim.x * rpi;
+        long long r = (long long)blockIdx.x * rpi + rsub;
+        for (; r + (BN_UNROLL - 1) * step < P; r += BN_UNROLL * step) {
+            float v[BN_UNROLL][NE];
+#pragma unroll
+            for (int u = 0; u < BN_UNROLL; ++u) BnIO<T, NE>::load(x + (r + u * step) * C + chunk * NE, v[u]);
+#pragma unroll
+            for (int u = 0; u < BN_UNROLL; ++u)
+#pragma unroll
+                for (int i = 0; i < NE; ++i) {
+                    const float d = v[u][i] - piv[i];
+                    acc[0][i] += d;
+                    acc[1][i] += d * d;
+                }
+        }
+        for (; r < P; r += step) {
             float v[NE];
             BnIO<T, NE>::load(x + r * C + chunk * NE, v);
 #pragma unroll
@@ -176,54 +196,95 @@ template <typename TI, typename TO>
 __global__ __launch_bounds__(BN_THREADS) void rowbn_apply_kernel(
     const TI *__restrict__ x, long long P, int C, const float *__restrict__ mean,
     const float *__restrict__ rstd, const float *__restrict__ gamma, const float *__restrict__ beta,
-    float slope, TO *__restrict__ y, unsigned total) {
+    float slope, TO *__restrict__ y) {
     constexpr int NE = (sizeof(TI) == 2 || sizeof(TO) == 2) ? 8 : 4;
-    const unsigned cpr = (unsigned)C / NE;
-    for (unsigned t = blockIdx.x * BN_THREADS + threadIdx.x; t < total; t += gridDim.x * BN_THREADS) {
-        const unsigned row = t / cpr, col = (t - row * cpr) * NE;
-        float v[NE];
-        BnIO<TI, NE>::load(x + (size_t)row * C + col, v);
+    const int cpr = C / NE, rpi = BN_THREADS / cpr;
+    const int chunk = threadIdx.x % cpr, rsub = threadIdx.x / cpr, col = chunk * NE;
+    if (rsub >= rpi) return;
+    float a[NE], b[NE], mu[NE];
 #pragma unroll
-        for (int i = 0; i < NE; ++i) {
-            const float a = (gamma ? gamma[col + i] : 1.0f) * rstd[col + i];
-            v[i] = lrelu_f(bn_z(v[i], mean[col + i], a, beta ? beta[col + i] : 0.0f), slope);
+    for (int i = 0; i < NE; ++i) {
+        mu[i] = mean[col + i];
+        a[i] = (gamma ? gamma[col + i] : 1.0f) * rstd[col + i];
+        b[i] = beta ? beta[col + i] : 0.0f;
+    }
+    const long long step = (long long)gridDim.x * rpi;
+    long long r = (long long)blockIdx.x * rpi + rsub;
+    for (; r + (BN_UNROLL - 1) * step < P; r += BN_UNROLL * step) {
+        float v[BN_UNROLL][NE];
+#pragma unroll
+        for (int u = 0; u < BN_UNROLL; ++u) BnIO<TI, NE>::load(x + (r + u * step) * C + col, v[u]);
+#pragma unroll
+        for (int u = 0; u < BN_UNROLL; ++u) {
+#pragma unroll
+            for (int i = 0; i < NE; ++i) v[u][i] = lrelu_f(bn_z(v[u][i], mu[i], a[i], b[i]), slope);
+            BnIO<TO, NE>::store(y + (r + u * step) * C + col, v[u]);
         }
-        BnIO<TO, NE>::store(y + (size_t)row * C + col, v);
+    }
+    for (; r < P; r += step) {
+        float v[NE];
+        BnIO<TI, NE>::load(x + r * C + col, v);
+#pragma unroll
+        for (int i = 0; i < NE; ++i) v[i] = lrelu_f(bn_z(v[i], mu[i], a[i], b[i]), slope);
+        BnIO<TO, NE>::store(y + r * C + col, v);
     }
 }
 
 // groups of K consecutive rows -> one row (max) + arg-max byte per channel (first maximum)
 template <typename TI, typename TO>
 __global__ __launch_bounds__(BN_THREADS) void rowbn_apply_max_kernel(
-    const TI *__restrict__ x, int K, int C, const float *__restrict__ mean, const float *__restrict__ rstd,
-    const float *__restrict__ gamma, const float *__restrict__ beta, float slope, TO *__restrict__ y,
-    uint8_t *__restrict__ arg, unsigned total) {
+    const TI *__restrict__ x, long long Gp, int K, int C, const float *__restrict__ mean,
+    const float *__restrict__ rstd, const float *__restrict__ gamma, const float *__restrict__ beta,
+    float slope, TO *__restrict__ y, uint8_t *__restrict__ arg) {
     constexpr int NE = (sizeof(TI) == 2 || sizeof(TO) == 2) ? 8 : 4;
-    const unsigned cpr = (unsigned)C / NE;
-    for (unsigned t = blockIdx.x * BN_THREADS + threadIdx.x; t < total; t += gridDim.x * BN_THREADS) {
-        const unsigned grp = t / cpr, col = (t - grp * cpr) * NE;
-        float a[NE], b[NE], mu[NE], best[NE];
+    const int cpr = C / NE, rpi = BN_THREADS / cpr;
+    const int chunk = threadIdx.x % cpr, rsub = threadIdx.x / cpr, col = chunk * NE;
+    if (rsub >= rpi) return;
+    float a[NE], b[NE], mu[NE];
+#pragma unroll
+    for (int i = 0; i < NE; ++i) {
+        mu[i] = mean[col + i];
+        a[i] = (gamma ? gamma[col + i] : 1.0f) * rstd[col + i];
+        b[i] = beta ? beta[col + i] : 0.0f;
+    }
+    for (long long grp = (long long)blockIdx.x * rpi + rsub; grp < Gp; grp += (long long)gridDim.x * rpi) {
+        float best[NE];
         int bk[NE];
 #pragma unroll
-        for (int i = 0; i < NE; ++i) {
-            a[i] = (gamma ? gamma[col + i] : 1.0f) * rstd[col + i];
-            b[i] = beta ? beta[col + i] : 0.0f;
-            mu[i] = mean[col + i];
-            best[i] = -INFINITY;
-            bk[i] = 0;
+        for (int i = 0; i < NE; ++i) { best[i] = -INFINITY; bk[i] = 0; }
+        const TI *xg = x + grp * K * C + col;
+        int k = 0;
+        for (; k + BN_UNROLL <= K; k += BN_UNROLL) {
+            float v[BN_UNROLL][NE];
+#pragma unroll
+            for (int u = 0; u < BN_UNROLL; ++u) BnIO<TI, NE>::load(xg + (size_t)(k + u) * C, v[u]);
+#pragma unroll
+            for (int u = 0; u < BN_UNROLL; ++u)
+#pragma unroll
+                for (int i = 0; i < NE; ++i) {
+                    const float z = lrelu_f(bn_z(v[u][i], mu[i], a[i], b[i]), slope);
+                    if (z > best[i]) { best[i] = z; bk[i] = k + u; }
+                }
         }
-        for (int k = 0; k < K; ++k) {
+        for (; k < K; ++k) {
             float v[NE];
-            BnIO<TI, NE>::load(x + ((size_t)grp * K + k) * C + col, v);
+            BnIO<TI, NE>::load(xg + (size_t)k * C, v);
 #pragma unroll
             for (int i = 0; i < NE; ++i) {
                 const float z = lrelu_f(bn_z(v[i], mu[i], a[i], b[i]), slope);
                 if (z > best[i]) { best[i] = z; bk[i] = k; }
             }
         }
-        BnIO<TO, NE>::store(y + (size_t)grp * C + col, best);
-#pragma unroll
-        for (int i = 0; i < NE; ++i) arg[(size_t)grp * C + col + i] = (uint8_t)bk[i];
+        BnIO<TO, NE>::store(y + grp * C + col, best);
+        // NE arg-max bytes (8-byte aligned for NE = 8, 4-byte for NE = 4)
+        if constexpr (NE == 8) {
+            const unsigned lo = bk[0] | (bk[1] << 8) | (bk[2] << 16) | ((unsigned)bk[3] << 24);
+            const unsigned hi = bk[4] | (bk[5] << 8) | (bk[6] << 16) | ((unsigned)bk[7] << 24);
+            *reinterpret_cast<uint2 *>(arg + grp * C + col) = make_uint2(lo, hi);
+        } else {
+            *reinterpret_cast<unsigned *>(arg + grp * C + col) =
+                bk[0] | (bk[1] << 8) | (bk[2] << 16) | ((unsigned)bk[3] << 24);
+        }
     }
 }
 
@@ -248,7 +309,26 @@ __global__ __launch_bounds__(BN_THREADS) void rowbn_bwd_reduce_kernel(
         b[i] = beta ? beta[c] : 0.0f;
     }
     if (rsub < rpi) {
-        for (long long r = (long long)blockIdx.x * rpi + rsub; r < P; r += (long long)gridDim.x * rpi) {
+        const long long step = (long long)gridDim.x * rpi;
+        long long r = (long long)blockIdx.x * rpi + rsub;
+        constexpr int U = 2;
+        for (; r + (U - 1) * step < P; r += U * step) {
+            float v[U][NE], g[U][NE];
+#pragma unroll
+            for (int u = 0; u < U; ++u) {
+                BnIO<TI, NE>::load(x + (r + u * step) * C + chunk * NE, v[u]);
+                BnIO<TG, NE>::load(gy + (r + u * step) * C + chunk * NE, g[u]);
+            }
+#pragma unroll
+            for (int u = 0; u < U; ++u)
+#pragma unroll
+                for (int i = 0; i < NE; ++i) {
+                    const float gg = bn_z(v[u][i], mu[i], a[i], b[i]) > 0.0f ? g[u][i] : g[u][i] * slope;
+                    acc[0][i] += gg;
+                    acc[1][i] += gg * ((v[u][i] - mu[i]) * rs[i]);
+                }
+        }
+        for (; r < P; r += step) {
             float v[NE], g[NE];
             BnIO<TI, NE>::load(x + r * C + chunk * NE, v);
             BnIO<TG, NE>::load(gy + r * C + chunk * NE, g);
@@ -318,41 +398,85 @@ __global__ __launch_bounds__(BN_THREADS) void rowbn_bwd_finalize_kernel(const fl
 // dx = a * (g - c1 - xhat*c2); K > 0: g lives only on each group's arg-max row
 template <typename TI, typename TG>
 __global__ __launch_bounds__(BN_THREADS) void rowbn_bwd_apply_kernel(
-    const TG *__restrict__ gy, const TI *__restrict__ x, const uint8_t *__restrict__ arg, int K, int C,
-    const float *__restrict__ mean, const float *__restrict__ rstd, const float *__restrict__ gamma,
-    const float *__restrict__ beta, float slope, const float *__restrict__ c12, TI *__restrict__ dx,
-    unsigned total) {
+    const TG *__restrict__ gy, const TI *__restrict__ x, const uint8_t *__restrict__ arg, long long P, int K,
+    int C, const float *__restrict__ mean, const float *__restrict__ rstd, const float *__restrict__ gamma,
+    const float *__restrict__ beta, float slope, const float *__restrict__ c12, TI *__restrict__ dx) {
     constexpr int NE = (sizeof(TI) == 2 || sizeof(TG) == 2) ? 8 : 4;
-    const unsigned cpr = (unsigned)C / NE;
-    for (unsigned t = blockIdx.x * BN_THREADS + threadIdx.x; t < total; t += gridDim.x * BN_THREADS) {
-        const unsigned row = t / cpr, col = (t - row * cpr) * NE;
-        float v[NE], g[NE];
-        BnIO<TI, NE>::load(x + (size_t)row * C + col, v);
-        unsigned k = 0;
-        size_t grow = row;
-        if (K > 0) { grow = row / (unsigned)K; k = row - (unsigned)grow * K; }
-        BnIO<TG, NE>::load(gy + grow * C + col, g);
+    const int cpr = C / NE, rpi = BN_THREADS / cpr;
+    const int chunk = threadIdx.x % cpr, rsub = threadIdx.x / cpr, col = chunk * NE;
+    if (rsub >= rpi) return;
+    float a[NE], b[NE], mu[NE], rs[NE], c1[NE], c2[NE];
 #pragma unroll
-        for (int i = 0; i < NE; ++i) {
-            const int c = col + i;
-            const float rs = rstd[c], mu = mean[c];
-            const float a = (gamma ? gamma[c] : 1.0f) * rs;
-            float gg = bn_z(v[i], mu, a, beta ? beta[c] : 0.0f) > 0.0f ? g[i] : g[i] * slope;
-            if (K > 0 && arg[grow * C + c] != k) gg = 0.0f;
-            v[i] = a * (gg - c12[c] - (v[i] - mu) * rs * c12[C + c]);
+    for (int i = 0; i < NE; ++i) {
+        mu[i] = mean[col + i];
+        rs[i] = rstd[col + i];
+        a[i] = (gamma ? gamma[col + i] : 1.0f) * rs[i];
+        b[i] = beta ? beta[col + i] : 0.0f;
+        c1[i] = c12[col + i];
+        c2[i] = c12[C + col + i];
+    }
+    const long long step = (long long)gridDim.x * rpi;
+    if (K == 0) {
+        constexpr int U = 2;
+        long long r = (long long)blockIdx.x * rpi + rsub;
+        for (; r + (U - 1) * step < P; r += U * step) {
+            float v[U][NE], g[U][NE];
+#pragma unroll
+            for (int u = 0; u < U; ++u) {
+                BnIO<TI, NE>::load(x + (r + u * step) * C + col, v[u]);
+                BnIO<TG, NE>::load(gy + (r + u * step) * C + col, g[u]);
+            }
+#pragma unroll
+            for (int u = 0; u < U; ++u) {
+#pragma unroll
+                for (int i = 0; i < NE; ++i) {
+                    const float gg = bn_z(v[u][i], mu[i], a[i], b[i]) > 0.0f ? g[u][i] : g[u][i] * slope;
+                    v[u][i] = a[i] * (gg - c1[i] - (v[u][i] - mu[i]) * rs[i] * c2[i]);
+                }
+                BnIO<TI, NE>::store(dx + (r + u * step) * C + col, v[u]);
+            }
         }
-        BnIO<TI, NE>::store(dx + (size_t)row * C + col, v);
+        for (; r < P; r += step) {
+            float v[NE], g[NE];
+            BnIO<TI, NE>::load(x + r * C + col, v);
+            BnIO<TG, NE>::load(gy + r * C + col, g);
+#pragma unroll
+            for (int i = 0; i < NE; ++i) {
+                const float gg = bn_z(v[i], mu[i], a[i], b[i]) > 0.0f ? g[i] : g[i] * slope;
+                v[i] = a[i] * (gg - c1[i] - (v[i] - mu[i]) * rs[i] * c2[i]);
+            }
+            BnIO<TI, NE>::store(dx + r * C + col, v);
+        }
+        return;
+    }
+    // K > 0: walk whole groups so that gy / arg-max are read once per group
+    const long long Gp = P / K;
+    for (long long grp = (long long)blockIdx.x * rpi + rsub; grp < Gp; grp += step) {
+        float g[NE];
+        int ak[NE];
+        BnIO<TG, NE>::load(gy + grp * C + col, g);
+#pragma unroll
+        for (int i = 0; i < NE; ++i) ak[i] = arg[grp * C + col + i];
+        for (int k = 0; k < K; ++k) {
+            float v[NE];
+            BnIO<TI, NE>::load(x + (grp * K + k) * C + col, v);
+#pragma unroll
+            for (int i = 0; i < NE; ++i) {
+                float gg = 0.0f;
+                if (ak[i] == k) gg = bn_z(v[i], mu[i], a[i], b[i]) > 0.0f ? g[i] : g[i] * slope;
+                v[i] = a[i] * (gg - c1[i] - (v[i] - mu[i]) * rs[i] * c2[i]);
+            }
+            BnIO<TI, NE>::store(dx + (grp * K + k) * C + col, v);
+        }
     }
 }
 
-int stats_blocks(long long rows, int rpi) {
-    long long b = (rows + (long long)rpi * 8 - 1) / ((long long)rpi * 8);  // >= 8 rows per thread
-    return (int)(b < 1 ? 1 : (b > BN_MAX_BLOCKS ? BN_MAX_BLOCKS : b));
+// workgroups for a row walk: >= `per_thread` rows per thread, at most `cap` workgroups
+int row_blocks(long long rows, int rpi, int per_thread, int cap) {
+    long long b = (rows + (long long)rpi * per_thread - 1) / ((long long)rpi * per_thread);
+    return (int)(b < 1 ? 1 : (b > cap ? cap : b));
 }
-unsigned ew_blocks(unsigned total) {
-    const unsigned b = (total + BN_THREADS - 1) / BN_THREADS;
-    return b < 1u ? 1u : (b > 16384u ? 16384u : b);
-}
+int stats_blocks(long long rows, int rpi) { return row_blocks(rows, rpi, 2 * BN_UNROLL, BN_MAX_BLOCKS); }
 bool bn_shape_ok(int dtype_a, int dtype_b, int C) {
     const int ne = (dtype_a == TPG_DTYPE_BF16 || dtype_b == TPG_DTYPE_BF16) ? 8 : 4;
     return C > 0 && C % ne == 0 && C / 4 <= BN_THREADS;   // <= 1024 channels (column-sum layout)
@@ -394,19 +518,18 @@ extern "C" int tpg_rowbn_fwd(const void *x, int dtype_in, long long P, int K, in
         }
     }  // eval mode: the caller has filled mean / rstd from the running statistics
     const int ne = (dtype_in == TPG_DTYPE_BF16 || dtype_out == TPG_DTYPE_BF16) ? 8 : 4;
+    const int rpi_a = BN_THREADS / (C / ne);
     const long long rows_out = K > 0 ? P / K : P;
-    const unsigned long long total64 = (unsigned long long)rows_out * (C / ne);
-    if (total64 >= 0x7fffffffULL) return TPG_ERR_ARG;
-    const unsigned total = (unsigned)total64;
-    const dim3 g(ew_blocks(total)), blk(BN_THREADS);
+    const dim3 g(K > 0 ? row_blocks(rows_out, rpi_a, 1, 8192) : row_blocks(P, rpi_a, BN_UNROLL, 4096));
+    const dim3 blk(BN_THREADS);
 #define TPG_BN_APPLY(TI, TO)                                                                              \
     do {                                                                                                  \
         if (K > 0)                                                                                        \
-            hipLaunchKernelGGL((rowbn_apply_max_kernel<TI, TO>), g, blk, 0, st, static_cast<const TI *>(x), K, C, \
-                               mean, rstd, gamma, beta, slope, static_cast<TO *>(y), argmax, total);      \
+            hipLaunchKernelGGL((rowbn_apply_max_kernel<TI, TO>), g, blk, 0, st, static_cast<const TI *>(x), \
+                               rows_out, K, C, mean, rstd, gamma, beta, slope, static_cast<TO *>(y), argmax); \
         else                                                                                              \
             hipLaunchKernelGGL((rowbn_apply_kernel<TI, TO>), g, blk, 0, st, static_cast<const TI *>(x), P, C, mean, \
-                               rstd, gamma, beta, slope, static_cast<TO *>(y), total);                    \
+                               rstd, gamma, beta, slope, static_cast<TO *>(y));                           \
     } while (0)
     if (dtype_in == TPG_DTYPE_F32 && dtype_out == TPG_DTYPE_F32) TPG_BN_APPLY(float, float);
     else if (dtype_in == TPG_DTYPE_F32) TPG_BN_APPLY(float, __hip_bfloat16);
@@ -434,9 +557,7 @@ extern "C" int tpg_rowbn_bwd(const void *gy, int dtype_g, const void *x, int dty
     const int rpi = BN_THREADS / (C / ne);
     const long long rows_g = K > 0 ? P / K : P;
     const int G = stats_blocks(rows_g, rpi);
-    const unsigned long long total64 = (unsigned long long)P * (C / ne);
-    if (total64 >= 0x7fffffffULL) return TPG_ERR_ARG;
-    const unsigned total = (unsigned)total64;
+    const int GA = K > 0 ? row_blocks(rows_g, rpi, 1, 8192) : row_blocks(P, rpi, 4, 4096);
 #define TPG_BN_BWD(TI, TG)                                                                                  \
     do {                                                                                                    \
         const TI *xx = static_cast<const TI *>(x);                                                          \
@@ -449,8 +570,8 @@ extern "C" int tpg_rowbn_bwd(const void *gy, int dtype_g, const void *x, int dty
                                mean, rstd, gamma, beta, slope, part);                                       \
         hipLaunchKernelGGL(rowbn_bwd_finalize_kernel, dim3((C + 15) / 16), dim3(BN_THREADS), 0, st, part, G, P, C, training, \
                            dgamma, dbeta, c12);                                                             \
-        hipLaunchKernelGGL((rowbn_bwd_apply_kernel<TI, TG>), dim3(ew_blocks(total)), dim3(BN_THREADS), 0, st, gg, \
-                           xx, argmax, K, C, mean, rstd, gamma, beta, slope, c12, static_cast<TI *>(dx), total); \
+        hipLaunchKernelGGL((rowbn_bwd_apply_kernel<TI, TG>), dim3(GA), dim3(BN_THREADS), 0, st, gg, xx, argmax, \
+                           P, K, C, mean, rstd, gamma, beta, slope, c12, static_cast<TI *>(dx));          \
     } while (0)
     if (dtype_in == TPG_DTYPE_F32 && dtype_g == TPG_DTYPE_F32) TPG_BN_BWD(float, float);
     else if (dtype_in == TPG_DTYPE_F32) TPG_BN_BWD(float, __hip_bfloat16);
