@@ -153,6 +153,17 @@ int tpg_rowbn_bwd(const void *gy, int dtype_g, const void *x, int dtype_in, cons
                   const float *gamma, const float *beta, float slope, float *dgamma, float *dbeta,
                   void *dx, void *ws, void *stream);
 
+/* ---- fused spectral normalisation of a (R x Cn) conv / linear weight ------------------------
+ * torch.nn.utils.spectral_norm's forward pre-hook (n_power_iterations = 1) on every conv and
+ * linear of the discriminators (discriminator.py:66-68,246-247,351-359,...) in ONE launch:
+ *   iterate != 0 (training):  v <- normalize(W^T u); u <- normalize(W v)   (u, v updated in place)
+ *   sigma = u . (W v);  Wsn = W / sigma.      normalize(x) = x / max(|x|_2, eps)
+ * backward, u and v constants:  dW = (G - <G, Wsn> u v^T) / sigma. */
+int tpg_spectral_norm_fwd(const float *W, float *u, float *v, int R, int Cn, int iterate, float eps,
+                          float *Wsn, float *sigma, void *stream);
+int tpg_spectral_norm_bwd(const float *G, const float *Wsn, const float *u, const float *v,
+                          const float *sigma, int R, int Cn, float *dW, void *stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -243,3 +243,21 @@ def rowbn_bwd(gy, x, arg, K, training, mean, rstd, gamma, beta, slope):
     else:
         dx = g_ * rstd * g
     return dx.astype(np.float32), dgamma.astype(np.float32), dbeta.astype(np.float32)
+
+
+# ---- spectral norm (torch.nn.utils.spectral_norm's forward pre-hook, n_power_iterations = 1) ----
+def spectral_norm_fwd(W, u, v, iterate, eps=1e-12):
+    W64, u64, v64 = np.asarray(W, np.float64), np.asarray(u, np.float64), np.asarray(v, np.float64)
+    if iterate:
+        t = W64.T @ u64
+        v64 = t / max(np.linalg.norm(t), eps)
+        s = W64 @ v64
+        u64 = s / max(np.linalg.norm(s), eps)
+    sigma = u64 @ (W64 @ v64)
+    return (W64 / sigma).astype(np.float32), u64.astype(np.float32), v64.astype(np.float32), np.float32(sigma)
+
+
+def spectral_norm_bwd(G, Wsn, u, v, sigma):
+    G64, W64 = np.asarray(G, np.float64), np.asarray(Wsn, np.float64)
+    d = (G64 * W64).sum()
+    return ((G64 - d * np.outer(u, v)) / float(sigma)).astype(np.float32)

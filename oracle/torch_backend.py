@@ -105,6 +105,18 @@ class OracleBackend:
         return _t(dx).to(x.dtype), (_t(dg) if need_affine else None), (_t(db) if need_affine else None)
 
 
+    # ---- fused spectral norm ------------------------------------------------------------
+    def spectral_norm_fwd(self, W, u, v, iterate, eps):
+        Wsn, u2, v2, sigma = R.spectral_norm_fwd(_np(W), _np(u), _np(v), iterate, eps)
+        if iterate:
+            u.copy_(_t(u2))
+            v.copy_(_t(v2))
+        return _t(Wsn), torch.tensor([float(sigma)])
+
+    def spectral_norm_bwd(self, G, Wsn, u, v, sigma):
+        return _t(R.spectral_norm_bwd(_np(G), _np(Wsn), _np(u), _np(v), float(sigma)))
+
+
 def install():
     import tpgan_amd.ops as ops
     ops.register_backend("cpu", OracleBackend())

@@ -558,18 +558,25 @@ extern "C" int tpg_rowbn_bwd(const void *gy, int dtype_g, const void *x, int dty
     const long long rows_g = K > 0 ? P / K : P;
     const int G = stats_blocks(rows_g, rpi);
     const int GA = K > 0 ? row_blocks(rows_g, rpi, 1, 8192) : row_blocks(P, rpi, 4, 4096);
+    // no batch statistics and no affine gradients wanted (pure activation [+max]): dx = a * g,
+    // nothing to reduce
+    const bool need_reduce = training || dgamma || dbeta;
+    if (!need_reduce && hipMemsetAsync(c12, 0, sizeof(float) * 2 * (size_t)C, st) != hipSuccess)
+        return TPG_ERR_LAUNCH;
 #define TPG_BN_BWD(TI, TG)                                                                                  \
     do {                                                                                                    \
         const TI *xx = static_cast<const TI *>(x);                                                          \
         const TG *gg = static_cast<const TG *>(gy);                                                         \
-        if (K > 0)                                                                                          \
+        if (!need_reduce) {                                                                                 \
+        } else if (K > 0)                                                                                   \
             hipLaunchKernelGGL((rowbn_bwd_reduce_max_kernel<TI, TG>), dim3(G), dim3(BN_THREADS), 0, st, gg, xx, \
                                argmax, rows_g, K, C, mean, rstd, gamma, beta, slope, part);                 \
         else                                                                                                \
             hipLaunchKernelGGL((rowbn_bwd_reduce_kernel<TI, TG>), dim3(G), dim3(BN_THREADS), 0, st, gg, xx, P, C, \
                                mean, rstd, gamma, beta, slope, part);                                       \
-        hipLaunchKernelGGL(rowbn_bwd_finalize_kernel, dim3((C + 15) / 16), dim3(BN_THREADS), 0, st, part, G, P, C, training, \
-                           dgamma, dbeta, c12);                                                             \
+        if (need_reduce)                                                                                    \
+            hipLaunchKernelGGL(rowbn_bwd_finalize_kernel, dim3((C + 15) / 16), dim3(BN_THREADS), 0, st, part, G, P, C, \
+                               training, dgamma, dbeta, c12);                                               \
         hipLaunchKernelGGL((rowbn_bwd_apply_kernel<TI, TG>), dim3(GA), dim3(BN_THREADS), 0, st, gg, xx, argmax, \
                            P, K, C, mean, rstd, gamma, beta, slope, c12, static_cast<TI *>(dx));          \
     } while (0)

@@ -107,9 +107,74 @@ def conv_bn_layer(in_feat, out_feat, act=False, norm="batch", sn=False):
     return nn.Sequential(*layers)
 
 
+class _TallLinear(torch.autograd.Function):
+    """y = x @ W^T for TALL x (P rows >> C): same forward GEMM as F.linear, but the weight
+    gradient dW = gy^T x -- a (Cout x Cin) output with K = P up to 2.6e5 -- is computed as a
+    split-K batched GEMM.  hipBLASLt maps the plain form to (Cout/64)*(Cin/64) = 4..16
+    workgroups on a 256-CU part (380 us per call measured); S slices of the row axis give
+    S*4..16 workgroups and finish in a few tens of us.  Partial products are summed in fp32."""
+
+    @staticmethod
+    def forward(ctx, x, w, dtype):
+        xd = x.to(dtype)
+        wd = w.to(dtype)
+        ctx.save_for_backward(xd, wd)
+        ctx.w_dtype = w.dtype
+        ctx.x_dtype = x.dtype
+        return xd @ wd.t()
+
+    @staticmethod
+    def backward(ctx, gy):
+        xd, wd = ctx.saved_tensors
+        gy = gy.to(xd.dtype)
+        dx = dw = None
+        if ctx.needs_input_grad[0]:
+            dx = (gy @ wd).to(ctx.x_dtype)
+        if ctx.needs_input_grad[1]:
+            P = xd.shape[0]
+            S = _split_k(P, wd.shape[0], wd.shape[1])
+            if S > 1:
+                rows = P // S
+                head = S * rows
+                part = torch.bmm(gy[:head].view(S, rows, -1).transpose(1, 2), xd[:head].view(S, rows, -1))
+                dw = part.float().sum(0)
+                if head < P:
+                    dw = dw + (gy[head:].t() @ xd[head:]).float()
+            else:
+                dw = (gy.t() @ xd).float()
+            dw = dw.to(ctx.w_dtype)
+        return dx, dw, None
+
+
+def _split_k(P, cout, cin):
+    """Slices of the row axis for the weight-gradient GEMM: aim at >= 512 workgroups of 64x64
+    output tiles, keep >= 1024 rows per slice."""
+    tiles = max(1, (cout + 63) // 64) * max(1, (cin + 63) // 64)
+    S = min(max(1, 512 // tiles), P // 1024)
+    return max(1, S)
+
+
+TALL_ROWS = 8192   # row counts from which the split-K weight gradient pays
+
+
+def rows_matmul(x, w, bias=None):
+    """x (...,Cin) @ w (Cout,Cin)^T [+ bias] on rows; tall inputs use the split-K backward."""
+    lead = x.shape[:-1]
+    P = x.numel() // x.shape[-1] if x.numel() else 0
+    if P >= TALL_ROWS and x.is_cuda and torch.is_grad_enabled() and w.requires_grad:
+        dtype = torch.get_autocast_gpu_dtype() if torch.is_autocast_enabled() else x.dtype
+        if dtype in (torch.float32, torch.bfloat16, torch.float16):
+            with torch.autocast(device_type="cuda", enabled=False):
+                y = _TallLinear.apply(x.reshape(P, x.shape[-1]), w, dtype)
+                if bias is not None:
+                    y = y + bias.to(y.dtype)
+            return y.view(*lead, w.shape[0])
+    return F.linear(x, w, bias)
+
+
 def rows_linear(conv, x):
     """Apply a bare 1x1 Conv2d (weight (Cout,Cin,1,1), optional bias) to rows (...,Cin)."""
-    return F.linear(x, conv.weight.view(conv.out_channels, -1), conv.bias)
+    return rows_matmul(x, conv.weight.view(conv.out_channels, -1), conv.bias)
 
 
 def rows_seq(seq, x):
@@ -206,6 +271,15 @@ class EdgeConv(nn.Module):
             E = rows_linear(self.edge_affine[0], xf)
         h = ops.row_combine(A, E, idx, ops.ROW_EDGE, slope=0.2, out_dtype=amp_dtype(x))   # (B,N,k,H)
         if self.mlp_layer:
+            mods = list(self.mlp)
+            C_out = mods[-2].out_channels if isinstance(mods[-2], nn.Conv2d) else 0
+            if (self.aggregate == "max" and isinstance(mods[-1], nn.LeakyReLU) and C_out % 8 == 0
+                    and 0 < C_out <= 1024 and h.shape[2] <= 256):
+                # last [LeakyReLU -> max over k] fused into one pass (ops.row_act_max)
+                y = rows_seq(mods[:-1], h)                              # (B,N,k,C_out), pre-activation
+                B, N, k, _ = y.shape
+                out = ops.row_act_max(y.reshape(B * N * k, C_out), mods[-1].negative_slope, k)
+                return out.view(B, N, C_out)
             return _agg(self.aggregate, rows_seq(self.mlp, h), 2)
         if self.aggregate in ("sum", "mean"):                           # linear commutes with sum
             return rows_seq(self.mlp, _agg(self.aggregate, h, 2))

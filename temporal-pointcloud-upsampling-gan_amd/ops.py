@@ -289,6 +289,23 @@ class HipBackend:
         return dx, dgamma, dbeta
 
 
+    # ---- fused spectral norm (csrc/spectral.hip) ------------------------------------------
+    def spectral_norm_fwd(self, W, u, v, iterate, eps):
+        R, Cn = W.shape
+        Wsn = torch.empty_like(W)
+        sigma = torch.empty(1, dtype=torch.float32, device=W.device)
+        self._call("tpg_spectral_norm_fwd", "spectral_norm_fwd", 4 * (2 * R * Cn + 2 * (R + Cn)), W,
+                   _ptr(W), _ptr(u), _ptr(v), R, Cn, int(iterate), float(eps), _ptr(Wsn), _ptr(sigma))
+        return Wsn, sigma
+
+    def spectral_norm_bwd(self, G, Wsn, u, v, sigma):
+        R, Cn = Wsn.shape
+        dW = torch.empty_like(Wsn)
+        self._call("tpg_spectral_norm_bwd", "spectral_norm_bwd", 4 * 3 * R * Cn, G,
+                   _ptr(G), _ptr(Wsn), _ptr(u), _ptr(v), _ptr(sigma), R, Cn, _ptr(dW))
+        return dW
+
+
 _DTYPE_CODE = {torch.float32: 0, torch.bfloat16: 1}
 _hip = None
 
@@ -608,3 +625,40 @@ def row_bn_act(x, gamma, beta, running_mean, running_var, training, momentum, ep
     b = None if beta is None else beta.float().contiguous()
     return _RowBNAct.apply(x.contiguous(), g, b, running_mean, running_var, bool(training), float(momentum),
                            float(eps), float(slope), int(K), out_dtype)
+
+
+def row_act_max(x, slope, K, out_dtype=None):
+    """max over each group of K consecutive rows of LeakyReLU(x): the [activation -> max over
+    the k neighbours] tail of an EdgeConv MLP (gcn_lib/pointnet/gcn.py:211) in one pass, with a
+    one-pass backward (same kernels as row_bn_act with identity statistics)."""
+    C_ = x.shape[1]
+    zeros = torch.zeros(C_, dtype=torch.float32, device=x.device)
+    ones = torch.ones(C_, dtype=torch.float32, device=x.device)
+    return row_bn_act(x, None, None, zeros, ones, False, 0.0, 0.0, slope, K, out_dtype)
+
+
+# ---------------------------------------------------------------------- fused spectral norm
+class _SpectralNorm(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, W, u, v, iterate, eps):
+        Wsn, sigma = backend_for(W).spectral_norm_fwd(W, u, v, iterate, eps)
+        # u, v as they are AFTER the power iteration (the constants of the backward)
+        ctx.save_for_backward(Wsn, u.clone(), v.clone(), sigma)
+        return Wsn
+
+    @staticmethod
+    def backward(ctx, G):
+        Wsn, u, v, sigma = ctx.saved_tensors
+        return backend_for(Wsn).spectral_norm_bwd(G.float().contiguous(), Wsn, u, v, sigma), None, None, None, None
+
+
+def spectral_normalize(weight_orig, u, v, training, eps=1e-12):
+    """W / sigma with one in-place power iteration of (u, v) in training mode -- the result of
+    torch.nn.utils.spectral_norm's forward pre-hook, in one kernel (include/tpgan_ops.h).
+    weight_orig (R, ...) fp32; returns a tensor of the same shape."""
+    _need(weight_orig.dtype == torch.float32 and u.dtype == torch.float32 and v.dtype == torch.float32,
+          "spectral_normalize works on fp32 parameters")
+    W2 = weight_orig.reshape(weight_orig.shape[0], -1).contiguous()
+    _need(u.numel() == W2.shape[0] and v.numel() == W2.shape[1] and u.is_contiguous() and v.is_contiguous(),
+          "u / v do not match the weight")
+    return _SpectralNorm.apply(W2, u, v, bool(training), float(eps)).view_as(weight_orig)

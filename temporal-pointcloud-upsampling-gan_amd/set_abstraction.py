@@ -28,7 +28,7 @@ import torch.nn.functional as F
 from torch.nn.utils import spectral_norm
 
 from . import ops
-from .graph_conv import amp_dtype, no_autocast, reference_order, rows_first  # noqa: F401
+from .graph_conv import amp_dtype, no_autocast, reference_order, rows_first, rows_matmul  # noqa: F401
 
 
 def knn(k, xyz1, xyz2):
@@ -67,17 +67,23 @@ def build_shared_mlp(mlp_spec: List[int], bn: bool = True, sn: bool = True, act_
     return nn.Sequential(*layers)
 
 
+def sn_weight(module):
+    """The weight a spectrally-normalised conv / linear would use in this forward: one power
+    iteration (training mode) + W / sigma, computed by ONE fused kernel on the module's own
+    `weight_orig` / `weight_u` / `weight_v` (ops.spectral_normalize) instead of PyTorch's
+    forward pre-hook (~12 launches forward, as many backward).  Always fp32, never autocast.
+    Modules without spectral norm return their plain weight."""
+    if not hasattr(module, "weight_orig"):
+        return module.weight
+    with torch.autocast(device_type=module.weight_orig.device.type, enabled=False):
+        return ops.spectral_normalize(module.weight_orig, module.weight_u, module.weight_v, module.training)
+
+
 def conv_weight2d(conv):
-    """(Cout,Cin) weight of a 1x1 conv AS THE MODULE CALL WOULD SEE IT: runs the module's
-    forward pre-hooks (old-style spectral norm: one power iteration in training mode and
-    `weight = weight_orig / sigma`, exactly once per forward as in the reference)."""
-    # the power iteration always runs in fp32: under bf16 autocast its mat-vec would be cast
-    # to bf16 (worse sigma estimate, and a 2.3 ms host-side rocBLAS bf16 gemv per call)
-    with torch.autocast(device_type=conv.weight_orig.device.type if hasattr(conv, "weight_orig")
-                        else conv.weight.device.type, enabled=False):
-        for hook in conv._forward_pre_hooks.values():
-            hook(conv, ())
-    return conv.weight.view(conv.weight.shape[0], -1)
+    """(Cout,Cin) weight of a 1x1 conv as its module call would see it (exactly one power
+    iteration per call, like the reference's one module call)."""
+    w = sn_weight(conv)
+    return w.view(w.shape[0], -1)
 
 
 def bn_rows(bn, x):
@@ -138,7 +144,7 @@ def mlp_tail_rows(layers, x, reduce_max=False):
     while i < n:
         m = layers[i]
         if isinstance(m, nn.Conv2d):
-            x = F.linear(x, conv_weight2d(m), m.bias)
+            x = rows_matmul(x, conv_weight2d(m), m.bias)
         elif isinstance(m, (nn.BatchNorm2d, nn.BatchNorm1d)):
             slope = _act_slope(layers[i + 1]) if i + 1 < n else None
             last = reduce_max and not any(isinstance(l, nn.Conv2d) for l in layers[i + 1:])
@@ -379,7 +385,7 @@ class FlowEmbedding(nn.Module):
         nl = len(self.mlp_convs)
         for l in range(nl):                                        # F.leaky_relu default slope 0.01
             if l:
-                x = F.linear(x, conv_weight2d(self.mlp_convs[l]))
+                x = rows_matmul(x, conv_weight2d(self.mlp_convs[l]))
             last = l == nl - 1
             if _fusable(x, K if last else 0):
                 x = bn_act_rows(self.mlp_bns[l], x, 0.01, K if last else 0)
@@ -444,10 +450,15 @@ def _head(dims, drops):
 
 
 def _head_fp32(fc_layers, x):
-    """The (B,C) classification head always runs in fp32 (B rows: nothing to gain from bf16,
-    and its spectral-norm hooks fire inside the module call)."""
+    """The (B,C) classification head, always in fp32 (B rows: nothing to gain from bf16);
+    spectrally-normalised linears use the fused kernel, everything else its own module."""
     with no_autocast(x):
-        return fc_layers(x.float())
+        x = x.float()
+        if not rows_first() or not isinstance(fc_layers, nn.Sequential):
+            return fc_layers(x)                       # reference order: PyTorch's own hooks
+        for m in fc_layers:
+            x = F.linear(x, sn_weight(m), m.bias) if isinstance(m, nn.Linear) else m(x)
+        return x
 
 
 class _TempoDis(nn.Module):

@@ -368,3 +368,36 @@ def test_rowbn_statistics_are_bitwise_reproducible(hip):
         hip.rowbn_fwd(x, 0, 1e-5, 0.1, True, None, None, None, None, 1.0, mean, rstd, torch.float32)
         outs.append((mean.clone(), rstd.clone()))
     assert all(torch.equal(outs[0][0], o[0]) and torch.equal(outs[0][1], o[1]) for o in outs[1:])
+
+
+# ------------------------------------------------------------------ fused spectral norm
+@pytest.mark.parametrize("R_,Cn", [(64, 6), (128, 131), (256, 515), (256, 259), (1, 64), (64, 256)])
+@pytest.mark.parametrize("iterate", [True, False])
+def test_spectral_norm_matches_oracle(hip, R_, Cn, iterate):
+    rng = np.random.default_rng(R_ + Cn)
+    W = rng.standard_normal((R_, Cn)).astype(np.float32)
+    u = rng.standard_normal(R_).astype(np.float32); u /= np.linalg.norm(u)
+    v = rng.standard_normal(Cn).astype(np.float32); v /= np.linalg.norm(v)
+    ud, vd = dev(u.copy()), dev(v.copy())
+    Wsn, sigma = hip.spectral_norm_fwd(dev(W), ud, vd, iterate, 1e-12)
+    rW, ru, rv, rs = R.spectral_norm_fwd(W, u, v, iterate)
+    assert abs(float(sigma) - float(rs)) <= 1e-5 * abs(float(rs))
+    assert np.abs(Wsn.cpu().numpy() - rW).max() <= 1e-5 * np.abs(rW).max()
+    assert np.abs(ud.cpu().numpy() - ru).max() <= 1e-5 and np.abs(vd.cpu().numpy() - rv).max() <= 1e-5
+    G = rng.standard_normal((R_, Cn)).astype(np.float32)
+    dW = hip.spectral_norm_bwd(dev(G), Wsn, ud, vd, sigma)
+    rdW = R.spectral_norm_bwd(G, rW, ru, rv, rs)
+    assert np.abs(dW.cpu().numpy() - rdW).max() <= 2e-5 * max(1.0, np.abs(rdW).max())
+
+
+def test_row_act_max_matches_torch(hip):
+    import tpgan_amd.ops as ops
+    x = torch.randn(4 * 64 * 20, 128, device="cuda", requires_grad=True)
+    y = ops.row_act_max(x, 0.2, 20)
+    ref = torch.nn.functional.leaky_relu(x.detach().view(256, 20, 128), 0.2).max(1)[0]
+    assert torch.equal(y, ref)
+    g = torch.randn_like(y)
+    y.backward(g)
+    xr = x.detach().clone().requires_grad_(True)
+    torch.nn.functional.leaky_relu(xr.view(256, 20, 128), 0.2).max(1)[0].backward(g)
+    assert torch.allclose(x.grad, xr.grad, atol=1e-6)
