@@ -164,6 +164,21 @@ int tpg_spectral_norm_fwd(const float *W, float *u, float *v, int R, int Cn, int
 int tpg_spectral_norm_bwd(const float *G, const float *Wsn, const float *u, const float *v,
                           const float *sigma, int R, int Cn, float *dW, void *stream);
 
+/* Batched form: every spectrally-normalised weight of one discriminator forward in ONE launch.
+ * desc: device array of M records {const float* W; float* u; float* v; int64 R, Cn, uses,
+ * out_off} (7 x 8 bytes).  Weight m is used `uses` times in the forward (once per frame / per
+ * flow-embedding pair); each use advances (u, v) by one power iteration (iterate != 0) and gets
+ * its own W / sigma.  For use t the kernel writes at out + out_off + t * stride(R, Cn) floats:
+ *   W/sigma_t (R*Cn) | u_t (R) | v_t (Cn) | sigma_t (1),  stride = tpg_spectral_norm_multi_stride.
+ * max_rc = max over m of (R + Cn).  u, v are left at their final values.
+ * Backward: desc of M records {float* dW; int64 R, Cn, uses, out_off, g_first} (6 x 8 bytes),
+ * gptr: device array of gradient pointers (NULL = no gradient for that use), use t of weight m
+ * at gptr[g_first + t]; dW[m] = sum_t (G_t - <G_t, Wsn_t> u_t v_t^T) / sigma_t. */
+long long tpg_spectral_norm_multi_stride(int R, int Cn);
+int tpg_spectral_norm_multi_fwd(const void *desc, int M, int max_rc, float *out, int iterate, float eps,
+                                void *stream);
+int tpg_spectral_norm_multi_bwd(const void *desc, const void *gptr, int M, const float *out, void *stream);
+
 #ifdef __cplusplus
 }
 #endif

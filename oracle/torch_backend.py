@@ -117,6 +117,46 @@ class OracleBackend:
         return _t(R.spectral_norm_bwd(_np(G), _np(Wsn), _np(u), _np(v), float(sigma)))
 
 
+    def spectral_norm_multi_fwd(self, Ws, us, vs, uses, iterate, eps):
+        from tpgan_amd.ops import sn_multi_stride
+        strides = [sn_multi_stride(W.shape[0], W.shape[1]) for W in Ws]
+        offs, total = [], 0
+        for st, n in zip(strides, uses):
+            offs.append(total)
+            total += st * n
+        flat = torch.zeros(total)
+        for W, u, v, n, off, st in zip(Ws, us, vs, uses, offs, strides):
+            R_, Cn = W.shape
+            for t in range(n):
+                Wsn, u2, v2, sigma = R.spectral_norm_fwd(_np(W), _np(u), _np(v), iterate, eps)
+                if iterate:
+                    u.copy_(_t(u2))
+                    v.copy_(_t(v2))
+                o = off + t * st
+                flat[o:o + R_ * Cn] = _t(Wsn).reshape(-1)
+                flat[o + R_ * Cn:o + R_ * Cn + R_] = _t(u2)
+                flat[o + R_ * Cn + R_:o + R_ * Cn + R_ + Cn] = _t(v2)
+                flat[o + R_ * Cn + R_ + Cn] = float(sigma)
+        return flat, list(zip(offs, strides)), None
+
+    def spectral_norm_multi_bwd(self, out, layout, shapes, uses, grads):
+        dWs, gi = [], 0
+        for (R_, Cn), n, (off, st) in zip(shapes, uses, layout):
+            dW = np.zeros((R_, Cn), np.float32)
+            for t in range(n):
+                g = grads[gi]
+                gi += 1
+                if g is None:
+                    continue
+                o = off + t * st
+                Wsn = _np(out[o:o + R_ * Cn]).reshape(R_, Cn)
+                u = _np(out[o + R_ * Cn:o + R_ * Cn + R_])
+                v = _np(out[o + R_ * Cn + R_:o + R_ * Cn + R_ + Cn])
+                dW += R.spectral_norm_bwd(_np(g), Wsn, u, v, float(out[o + R_ * Cn + R_ + Cn]))
+            dWs.append(_t(dW))
+        return dWs
+
+
 def install():
     import tpgan_amd.ops as ops
     ops.register_backend("cpu", OracleBackend())

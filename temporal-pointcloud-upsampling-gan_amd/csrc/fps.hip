@@ -151,12 +151,21 @@ template <int BLOCK, int PPT>
 void fps_go(const float *xyz, int B, int N, int m, int32_t *idx, hipStream_t st) {
     int use_lds = N <= FPS_LDS_POINTS;
     size_t smem = 256 + (use_lds ? sizeof(float) * 3 * (size_t)N : 0);
-    if (smem > 48 * 1024 &&
-        hipFuncSetAttribute(reinterpret_cast<const void *>(&fps_kernel<BLOCK, PPT, true>),
-                            hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem) != hipSuccess) {
-        (void)hipGetLastError();
-        use_lds = 0;  // read the selected point from L2 instead
-        smem = 256;
+    if (smem > 48 * 1024) {
+        // opt in to > 48 KiB of dynamic LDS once per instantiation (not a stream operation, so
+        // it must not happen inside a captured launch sequence): request the maximum this
+        // instantiation can ever need.
+        static int granted = -1;
+        if (granted < 0) {
+            const int want = 256 + (int)sizeof(float) * 3 * FPS_LDS_POINTS;
+            granted = hipFuncSetAttribute(reinterpret_cast<const void *>(&fps_kernel<BLOCK, PPT, true>),
+                                          hipFuncAttributeMaxDynamicSharedMemorySize, want) == hipSuccess;
+            if (!granted) (void)hipGetLastError();
+        }
+        if (!granted) {
+            use_lds = 0;  // read the selected point from L2 instead
+            smem = 256;
+        }
     }
     if (use_lds)
         hipLaunchKernelGGL((fps_kernel<BLOCK, PPT, true>), dim3(B), dim3(BLOCK), smem, st, xyz, N, m, idx);

@@ -25,7 +25,7 @@
 namespace {
 
 constexpr int BN_THREADS = 256;
-constexpr int BN_MAX_BLOCKS = 1024;  // partial rows per reduction (4 workgroups per CU)
+constexpr int BN_MAX_BLOCKS = 512;   // partial rows per reduction (2 workgroups per CU)
 
 // ---- 16-byte row chunks <-> NE floats (same helpers as rowgather.hip) ----------------------
 template <typename T, int NE> struct BnIO;
@@ -147,29 +147,40 @@ __global__ __launch_bounds__(BN_THREADS) void rowbn_stats_kernel(const T *__rest
     block_column_reduce<2, NE>(acc, cpr, rpi, C, part);
 }
 
-// Sum the per-workgroup partials of two quantities for 16 channels per workgroup: 16 lanes of
-// partial rows x 16 channels, fp64, one LDS step.  Returns true in the lane that owns channel c.
+// Sum the per-workgroup partials of two quantities: a workgroup owns FIN_CH channels, each
+// summed by 256/FIN_CH lanes over the partial rows (a handful of independent loads per lane,
+// not a 64-deep dependent chain), fp64, one LDS step.  True in the lane that owns channel c.
+constexpr int FIN_CH = 4;
+constexpr int FIN_LANES = BN_THREADS / FIN_CH;
 __device__ __forceinline__ bool finalize_sums(const float *__restrict__ part, int G, int C, int &c, double &s0,
                                               double &s1) {
-    __shared__ double red[2][16][16];
-    const int cl = threadIdx.x & 15, gl = threadIdx.x >> 4;
-    c = blockIdx.x * 16 + cl;
+    __shared__ double red[2][FIN_LANES][FIN_CH];
+    const int cl = threadIdx.x % FIN_CH, gl = threadIdx.x / FIN_CH;
+    c = blockIdx.x * FIN_CH + cl;
     double a0 = 0.0, a1 = 0.0;
     if (c < C)
-        for (int g = gl; g < G; g += 16) {
+        for (int g = gl; g < G; g += FIN_LANES) {
             a0 += part[((size_t)g * 2 + 0) * C + c];
             a1 += part[((size_t)g * 2 + 1) * C + c];
         }
     red[0][gl][cl] = a0;
     red[1][gl][cl] = a1;
     __syncthreads();
+    // tree over the FIN_LANES partial sums of each channel
+    for (int sft = FIN_LANES / 2; sft > 0; sft >>= 1) {
+        if (gl < sft) {
+            red[0][gl][cl] += red[0][gl + sft][cl];
+            red[1][gl][cl] += red[1][gl + sft][cl];
+        }
+        __syncthreads();
+    }
     if (gl != 0 || c >= C) return false;
-    s0 = 0.0; s1 = 0.0;
-    for (int r = 0; r < 16; ++r) { s0 += red[0][r][cl]; s1 += red[1][r][cl]; }
+    s0 = red[0][0][cl];
+    s1 = red[1][0][cl];
     return true;
 }
 
-// partials -> mean, rstd (+ running-stat update as nn.BatchNorm does); grid = ceil(C/16)
+// partials -> mean, rstd (+ running-stat update as nn.BatchNorm does); grid = ceil(C/FIN_CH)
 template <typename T>
 __global__ __launch_bounds__(BN_THREADS) void rowbn_stats_finalize_kernel(
     const T *__restrict__ x, const float *__restrict__ part, int G, long long P, int C, float eps,
@@ -380,7 +391,7 @@ __global__ __launch_bounds__(BN_THREADS) void rowbn_bwd_reduce_max_kernel(
     block_column_reduce<2, NE>(acc, cpr, rpi, C, part);
 }
 
-// partials -> dgamma, dbeta (fp32) and the two per-channel constants of dx; grid = ceil(C/16)
+// partials -> dgamma, dbeta (fp32) and the two per-channel constants of dx; grid = ceil(C/FIN_CH)
 __global__ __launch_bounds__(BN_THREADS) void rowbn_bwd_finalize_kernel(const float *__restrict__ part, int G,
                                                                         long long P, int C, int training,
                                                                         float *__restrict__ dgamma,
@@ -457,7 +468,23 @@ __global__ __launch_bounds__(BN_THREADS) void rowbn_bwd_apply_kernel(
         BnIO<TG, NE>::load(gy + grp * C + col, g);
 #pragma unroll
         for (int i = 0; i < NE; ++i) ak[i] = arg[grp * C + col + i];
-        for (int k = 0; k < K; ++k) {
+        int k = 0;
+        for (; k + BN_UNROLL <= K; k += BN_UNROLL) {
+            float v[BN_UNROLL][NE];
+#pragma unroll
+            for (int u = 0; u < BN_UNROLL; ++u) BnIO<TI, NE>::load(x + (grp * K + k + u) * C + col, v[u]);
+#pragma unroll
+            for (int u = 0; u < BN_UNROLL; ++u) {
+#pragma unroll
+                for (int i = 0; i < NE; ++i) {
+                    float gg = 0.0f;
+                    if (ak[i] == k + u) gg = bn_z(v[u][i], mu[i], a[i], b[i]) > 0.0f ? g[i] : g[i] * slope;
+                    v[u][i] = a[i] * (gg - c1[i] - (v[u][i] - mu[i]) * rs[i] * c2[i]);
+                }
+                BnIO<TI, NE>::store(dx + (grp * K + k + u) * C + col, v[u]);
+            }
+        }
+        for (; k < K; ++k) {
             float v[NE];
             BnIO<TI, NE>::load(x + (grp * K + k) * C + col, v);
 #pragma unroll
@@ -508,12 +535,12 @@ extern "C" int tpg_rowbn_fwd(const void *x, int dtype_in, long long P, int K, in
         if (dtype_in == TPG_DTYPE_BF16) {
             const __hip_bfloat16 *xx = static_cast<const __hip_bfloat16 *>(x);
             hipLaunchKernelGGL(rowbn_stats_kernel<__hip_bfloat16>, dim3(G), dim3(BN_THREADS), 0, st, xx, P, C, part);
-            hipLaunchKernelGGL(rowbn_stats_finalize_kernel<__hip_bfloat16>, dim3((C + 15) / 16), dim3(BN_THREADS), 0, st, xx,
+            hipLaunchKernelGGL(rowbn_stats_finalize_kernel<__hip_bfloat16>, dim3((C + FIN_CH - 1) / FIN_CH), dim3(BN_THREADS), 0, st, xx,
                                part, G, P, C, eps, momentum, running_mean, running_var, mean, rstd);
         } else {
             const float *xx = static_cast<const float *>(x);
             hipLaunchKernelGGL(rowbn_stats_kernel<float>, dim3(G), dim3(BN_THREADS), 0, st, xx, P, C, part);
-            hipLaunchKernelGGL(rowbn_stats_finalize_kernel<float>, dim3((C + 15) / 16), dim3(BN_THREADS), 0, st, xx, part, G,
+            hipLaunchKernelGGL(rowbn_stats_finalize_kernel<float>, dim3((C + FIN_CH - 1) / FIN_CH), dim3(BN_THREADS), 0, st, xx, part, G,
                                P, C, eps, momentum, running_mean, running_var, mean, rstd);
         }
     }  // eval mode: the caller has filled mean / rstd from the running statistics
@@ -575,7 +602,7 @@ extern "C" int tpg_rowbn_bwd(const void *gy, int dtype_g, const void *x, int dty
             hipLaunchKernelGGL((rowbn_bwd_reduce_kernel<TI, TG>), dim3(G), dim3(BN_THREADS), 0, st, gg, xx, P, C, \
                                mean, rstd, gamma, beta, slope, part);                                       \
         if (need_reduce)                                                                                    \
-            hipLaunchKernelGGL(rowbn_bwd_finalize_kernel, dim3((C + 15) / 16), dim3(BN_THREADS), 0, st, part, G, P, C, \
+            hipLaunchKernelGGL(rowbn_bwd_finalize_kernel, dim3((C + FIN_CH - 1) / FIN_CH), dim3(BN_THREADS), 0, st, part, G, P, C, \
                                training, dgamma, dbeta, c12);                                               \
         hipLaunchKernelGGL((rowbn_bwd_apply_kernel<TI, TG>), dim3(GA), dim3(BN_THREADS), 0, st, gg, xx, argmax, \
                            P, K, C, mean, rstd, gamma, beta, slope, c12, static_cast<TI *>(dx));          \

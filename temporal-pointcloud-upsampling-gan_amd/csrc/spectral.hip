@@ -101,7 +101,145 @@ __global__ __launch_bounds__(SN_THREADS) void spectral_norm_bwd_kernel(
     }
 }
 
+// ---- batched form: one workgroup per weight, `uses` chained power iterations each ----------
+// A discriminator forward calls every spectrally-normalised module once per frame (or per
+// flow-embedding pair), and each call advances (u, v) by one power iteration and uses its own
+// W / sigma.  desc[m] = {W, u, v, R, Cn, uses, out_off}: for use t the kernel writes, at
+// out + out_off + t * stride(R, Cn):  W/sigma_t (R*Cn) | u_t (R) | v_t (Cn) | sigma_t (1).
+struct SnDesc {
+    const float *W;
+    float *u;
+    float *v;
+    long long R, Cn, uses, out_off;
+};
+__host__ __device__ inline long long sn_stride(long long R, long long Cn) { return (R * Cn + R + Cn + 1 + 3) & ~3LL; }
+
+__global__ __launch_bounds__(SN_THREADS) void spectral_norm_multi_fwd_kernel(const SnDesc *__restrict__ desc,
+                                                                             float *__restrict__ out, int iterate,
+                                                                             float eps) {
+    extern __shared__ __attribute__((aligned(16))) float sn_smem[];
+    const SnDesc d = desc[blockIdx.x];
+    const int R = (int)d.R, Cn = (int)d.Cn;
+    const float *__restrict__ W = d.W;
+    float *su = sn_smem, *sv = sn_smem + R, *scratch = sn_smem + R + Cn;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    for (int i = tid; i < R; i += SN_THREADS) su[i] = d.u[i];
+    for (int j = tid; j < Cn; j += SN_THREADS) sv[j] = d.v[j];
+    __syncthreads();
+    const size_t n = (size_t)R * Cn;
+    for (int t = 0; t < (int)d.uses; ++t) {
+        float *o = out + d.out_off + (size_t)t * sn_stride(R, Cn);
+        float *ou = o + n, *ov = ou + R;
+        if (iterate) {
+            // t = W^T u: wave w takes rows w, w+16, ...; lanes take columns; partial column sums
+            // are combined through LDS (sv) with one atomic add per (wave, column)
+            for (int j = tid; j < Cn; j += SN_THREADS) sv[j] = 0.0f;
+            __syncthreads();
+            for (int j0 = 0; j0 < Cn; j0 += 64) {
+                const int j = j0 + lane;
+                float acc = 0.0f;
+                if (j < Cn)
+                    for (int i = wave; i < R; i += SN_THREADS / 64) acc += W[(size_t)i * Cn + j] * su[i];
+                if (j < Cn) atomicAdd(&sv[j], acc);
+            }
+            __syncthreads();
+            float nrm = 0.0f;
+            for (int j = tid; j < Cn; j += SN_THREADS) nrm += sv[j] * sv[j];
+            nrm = block_sum(nrm, scratch);
+            const float inv = 1.0f / fmaxf(sqrtf(nrm), eps);
+            for (int j = tid; j < Cn; j += SN_THREADS) sv[j] *= inv;
+            __syncthreads();
+        }
+        for (int i = wave; i < R; i += SN_THREADS / 64) {  // s = W v, wave per row
+            float sacc = 0.0f;
+            for (int j = lane; j < Cn; j += 64) sacc += W[(size_t)i * Cn + j] * sv[j];
+            sacc = wave_sum(sacc);
+            if (lane == 0) {
+                ou[i] = sacc;               // raw s = W v (eval mode reads it for sigma below)
+                if (iterate) su[i] = sacc;  // training: u <- s, normalised below
+            }
+        }
+        __syncthreads();
+        float sigma;
+        if (iterate) {
+            float nrm = 0.0f;
+            for (int i = tid; i < R; i += SN_THREADS) nrm += su[i] * su[i];
+            nrm = block_sum(nrm, scratch);
+            const float inv = 1.0f / fmaxf(sqrtf(nrm), eps);
+            sigma = nrm * inv;
+            for (int i = tid; i < R; i += SN_THREADS) su[i] *= inv;   // u <- s / |s|
+            __syncthreads();
+        } else {
+            float dsum = 0.0f;
+            for (int i = tid; i < R; i += SN_THREADS) dsum += su[i] * ou[i];
+            sigma = block_sum(dsum, scratch);
+        }
+        for (int i = tid; i < R; i += SN_THREADS) ou[i] = su[i];
+        for (int j = tid; j < Cn; j += SN_THREADS) ov[j] = sv[j];
+        for (size_t e = tid; e < n; e += SN_THREADS) o[e] = W[e] / sigma;
+        if (tid == 0) ov[Cn] = sigma;
+        __syncthreads();
+    }
+    if (iterate) {
+        for (int i = tid; i < R; i += SN_THREADS) d.u[i] = su[i];
+        for (int j = tid; j < Cn; j += SN_THREADS) d.v[j] = sv[j];
+    }
+}
+
+// gdesc[m*max_uses + t] = pointer to the gradient of use t (or null); dW[m] = sum over uses
+struct SnBwdDesc {
+    float *dW;
+    long long R, Cn, uses, out_off, g_first;
+};
+__global__ __launch_bounds__(SN_THREADS) void spectral_norm_multi_bwd_kernel(const SnBwdDesc *__restrict__ desc,
+                                                                             const float *const *__restrict__ gptr,
+                                                                             const float *__restrict__ out) {
+    __shared__ float scratch[16];
+    const SnBwdDesc d = desc[blockIdx.x];
+    const int R = (int)d.R, Cn = (int)d.Cn, tid = threadIdx.x;
+    const size_t n = (size_t)R * Cn;
+    for (size_t e = tid; e < n; e += SN_THREADS) d.dW[e] = 0.0f;
+    for (int t = 0; t < (int)d.uses; ++t) {
+        const float *G = gptr[d.g_first + t];
+        if (!G) continue;  // wave-uniform: this use did not receive a gradient
+        const float *o = out + d.out_off + (size_t)t * sn_stride(R, Cn);
+        const float *ou = o + n, *ov = ou + R;
+        const float sigma = ov[Cn];
+        float dot = 0.0f;
+        for (size_t e = tid; e < n; e += SN_THREADS) dot += G[e] * o[e];
+        dot = block_sum(dot, scratch);
+        for (size_t e = tid; e < n; e += SN_THREADS) {
+            const int i = (int)(e / Cn), j = (int)(e - (size_t)i * Cn);
+            d.dW[e] += (G[e] - dot * ou[i] * ov[j]) / sigma;
+        }
+    }
+}
+
 }  // namespace
+
+extern "C" long long tpg_spectral_norm_multi_stride(int R, int Cn) { return sn_stride(R, Cn); }
+
+extern "C" int tpg_spectral_norm_multi_fwd(const void *desc, int M, int max_rc, float *out, int iterate, float eps,
+                                           void *stream) {
+    if (M < 0 || !desc || !out) return TPG_ERR_ARG;
+    if (M == 0) return TPG_OK;
+    const size_t smem = sizeof(float) * ((size_t)max_rc + 64);
+    if (smem > 48 * 1024) return TPG_ERR_UNSUPPORTED;
+    hipLaunchKernelGGL(spectral_norm_multi_fwd_kernel, dim3(M), dim3(SN_THREADS), smem, tpg_stream(stream),
+                       static_cast<const SnDesc *>(desc), out, iterate, eps);
+    TPG_RETURN_IF_LAUNCH_FAILED();
+    return TPG_OK;
+}
+
+extern "C" int tpg_spectral_norm_multi_bwd(const void *desc, const void *gptr, int M, const float *out,
+                                           void *stream) {
+    if (M < 0 || !desc || !gptr || !out) return TPG_ERR_ARG;
+    if (M == 0) return TPG_OK;
+    hipLaunchKernelGGL(spectral_norm_multi_bwd_kernel, dim3(M), dim3(SN_THREADS), 0, tpg_stream(stream),
+                       static_cast<const SnBwdDesc *>(desc), static_cast<const float *const *>(gptr), out);
+    TPG_RETURN_IF_LAUNCH_FAILED();
+    return TPG_OK;
+}
 
 extern "C" int tpg_spectral_norm_fwd(const float *W, float *u, float *v, int R, int Cn, int iterate, float eps,
                                      float *Wsn, float *sigma, void *stream) {

@@ -118,6 +118,7 @@ class HipBackend:
 
     def __init__(self):
         self.lib = _lib.load()
+        self._ws = {}
 
     def _call(self, symbol, op, nbytes, ref, *args):
         fn = getattr(self.lib, symbol)
@@ -258,8 +259,15 @@ class HipBackend:
 
     # ---- fused BatchNorm + LeakyReLU (+ max over K) on rows (csrc/rowbn.hip) -------------
     def _bn_ws(self, x, C_):
-        n = self.lib.tpg_rowbn_workspace_bytes(C_)
-        return torch.empty(n // 4, dtype=torch.float32, device=x.device)
+        # one scratch buffer per (device, stream), reused by every call: launches on a stream are
+        # ordered, so the next call cannot start before the previous one has consumed it
+        key = (x.device, torch.cuda.current_stream(x.device).cuda_stream)
+        ws = self._ws.get(key)
+        need = self.lib.tpg_rowbn_workspace_bytes(max(C_, 256)) // 4
+        if ws is None or ws.numel() < need:
+            ws = torch.empty(need, dtype=torch.float32, device=x.device)
+            self._ws[key] = ws
+        return ws
 
     def rowbn_fwd(self, x, K, eps, momentum, training, running_mean, running_var, gamma, beta, slope,
                   mean, rstd, out_dtype):
@@ -304,6 +312,46 @@ class HipBackend:
         self._call("tpg_spectral_norm_bwd", "spectral_norm_bwd", 4 * 3 * R * Cn, G,
                    _ptr(G), _ptr(Wsn), _ptr(u), _ptr(v), _ptr(sigma), R, Cn, _ptr(dW))
         return dW
+
+
+    def spectral_norm_multi_fwd(self, Ws, us, vs, uses, iterate, eps):
+        """-> (flat buffer, [(offset, stride)] per weight); layout in include/tpgan_ops.h."""
+        dev = Ws[0].device
+        strides = [sn_multi_stride(W.shape[0], W.shape[1]) for W in Ws]
+        offs, total = [], 0
+        for st, n in zip(strides, uses):
+            offs.append(total)
+            total += st * n
+        rec = []
+        for W, u, v, n, off in zip(Ws, us, vs, uses, offs):
+            rec += [W.data_ptr(), u.data_ptr(), v.data_ptr(), W.shape[0], W.shape[1], n, off]
+        desc = torch.tensor(rec, dtype=torch.int64).to(dev, non_blocking=True)
+        out = torch.empty(total, dtype=torch.float32, device=dev)
+        max_rc = max(W.shape[0] + W.shape[1] for W in Ws)
+        nbytes = 4 * sum((1 + n) * W.numel() for W, n in zip(Ws, uses))
+        self._call("tpg_spectral_norm_multi_fwd", "spectral_norm_fwd", nbytes, out,
+                   _ptr(desc), len(Ws), max_rc, _ptr(out), int(iterate), float(eps))
+        return out, list(zip(offs, strides)), desc
+
+    def spectral_norm_multi_bwd(self, out, layout, shapes, uses, grads):
+        dev = out.device
+        dWs = [torch.empty(shp, dtype=torch.float32, device=dev) for shp in shapes]
+        rec, gp, first = [], [], 0
+        for dW, shp, n, (off, _st) in zip(dWs, shapes, uses, layout):
+            rec += [dW.data_ptr(), shp[0], shp[1], n, off, first]
+            first += n
+        for g in grads:
+            gp.append(0 if g is None else g.data_ptr())
+        desc = torch.tensor(rec, dtype=torch.int64).to(dev, non_blocking=True)
+        gptr = torch.tensor(gp, dtype=torch.int64).to(dev, non_blocking=True)
+        nbytes = 4 * sum((1 + 2 * n) * shp[0] * shp[1] for shp, n in zip(shapes, uses))
+        self._call("tpg_spectral_norm_multi_bwd", "spectral_norm_bwd", nbytes, out,
+                   _ptr(desc), _ptr(gptr), len(shapes), _ptr(out))
+        return dWs
+
+
+def sn_multi_stride(R, Cn):
+    return (R * Cn + R + Cn + 1 + 3) & ~3
 
 
 _DTYPE_CODE = {torch.float32: 0, torch.bfloat16: 1}
@@ -662,3 +710,47 @@ def spectral_normalize(weight_orig, u, v, training, eps=1e-12):
     _need(u.numel() == W2.shape[0] and v.numel() == W2.shape[1] and u.is_contiguous() and v.is_contiguous(),
           "u / v do not match the weight")
     return _SpectralNorm.apply(W2, u, v, bool(training), float(eps)).view_as(weight_orig)
+
+
+class _SpectralNormMulti(torch.autograd.Function):
+    """All spectrally-normalised weights of one forward pass, each used `uses[m]` times."""
+
+    @staticmethod
+    def forward(ctx, training, eps, uses, *tensors):
+        n = len(uses)
+        Ws, us, vs = tensors[:n], tensors[n:2 * n], tensors[2 * n:]
+        be = backend_for(Ws[0])
+        flat, layout, _ = be.spectral_norm_multi_fwd(list(Ws), list(us), list(vs), list(uses), training, eps)
+        outs = []
+        for W, (off, st), k in zip(Ws, layout, uses):
+            R, Cn = W.shape
+            for t in range(k):
+                outs.append(flat[off + t * st: off + t * st + R * Cn].view(R, Cn))
+        ctx.flat, ctx.layout, ctx.uses = flat, layout, tuple(uses)
+        ctx.shapes = [tuple(W.shape) for W in Ws]
+        return tuple(outs)
+
+    @staticmethod
+    def backward(ctx, *grads):
+        gs = [None if g is None else g.float().contiguous() for g in grads]
+        dWs = backend_for(ctx.flat).spectral_norm_multi_bwd(ctx.flat, ctx.layout, ctx.shapes, ctx.uses, gs)
+        n = len(ctx.uses)
+        return (None, None, None) + tuple(dWs) + (None,) * (2 * n)
+
+
+def spectral_normalize_many(modules, uses, training, eps=1e-12):
+    """For every spectrally-normalised module m (attributes weight_orig / weight_u / weight_v) the
+    `uses[m]` successive weights W / sigma its forward pre-hook would produce over that many calls
+    (one power iteration per call in training mode) -- all modules in ONE launch.
+    Returns a list (per module) of lists (per use) of 2-D weights (R, prod(rest))."""
+    Ws = [m.weight_orig.reshape(m.weight_orig.shape[0], -1) for m in modules]
+    for W in Ws:
+        _need(W.dtype == torch.float32 and W.is_contiguous(), "spectral norm works on contiguous fp32 weights")
+    us = [m.weight_u for m in modules]
+    vs = [m.weight_v for m in modules]
+    outs = _SpectralNormMulti.apply(bool(training), float(eps), tuple(int(k) for k in uses), *Ws, *us, *vs)
+    res, i = [], 0
+    for k in uses:
+        res.append(list(outs[i:i + k]))
+        i += k
+    return res

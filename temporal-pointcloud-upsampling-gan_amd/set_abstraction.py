@@ -19,6 +19,7 @@ weight, same single power iteration per call) is applied to the N un-grouped row
 (B,3+C,S,ns) tensor).  The remaining layers are GEMMs on channels-last rows with
 BatchNorm over the (B*S*ns) row axis -- the same statistics as BatchNorm2d over (B,S,ns).
 """
+import contextlib
 from typing import List
 
 import numpy as np
@@ -67,6 +68,28 @@ def build_shared_mlp(mlp_spec: List[int], bn: bool = True, sn: bool = True, act_
     return nn.Sequential(*layers)
 
 
+# weights prepared for the current discriminator forward: id(module) -> list of 2-D weights, one
+# per upcoming call (filled by sn_prefetch, consumed by sn_weight)
+_SN_READY = {}
+
+
+@contextlib.contextmanager
+def sn_prefetch(modules_and_uses, training):
+    """Compute, in ONE kernel launch, every spectrally-normalised weight the enclosed forward
+    will ask for: modules_and_uses = [(module, number_of_calls)], in any order."""
+    todo = [(m, k) for m, k in modules_and_uses if hasattr(m, "weight_orig") and k > 0]
+    if todo and rows_first():
+        with torch.autocast(device_type=todo[0][0].weight_orig.device.type, enabled=False):
+            ws = ops.spectral_normalize_many([m for m, _ in todo], [k for _, k in todo], training)
+        for (m, _), lst in zip(todo, ws):
+            _SN_READY[id(m)] = [w.view(m.weight_orig.shape) for w in lst]
+    try:
+        yield
+    finally:
+        for m, _ in todo:
+            _SN_READY.pop(id(m), None)
+
+
 def sn_weight(module):
     """The weight a spectrally-normalised conv / linear would use in this forward: one power
     iteration (training mode) + W / sigma, computed by ONE fused kernel on the module's own
@@ -75,6 +98,9 @@ def sn_weight(module):
     Modules without spectral norm return their plain weight."""
     if not hasattr(module, "weight_orig"):
         return module.weight
+    ready = _SN_READY.get(id(module))
+    if ready:
+        return ready.pop(0)
     with torch.autocast(device_type=module.weight_orig.device.type, enabled=False):
         return ops.spectral_normalize(module.weight_orig, module.weight_u, module.weight_v, module.training)
 
@@ -472,13 +498,25 @@ class _TempoDis(nn.Module):
         poss2, feats2 = self.coarse_graining_module[1].forward_rows_frames(poss, feats)
         return feats2, poss2
 
+    def _sn_calls(self, T):
+        """(module, calls in one forward over T frames) for every conv / linear."""
+        calls = []
+        for sa in self.coarse_graining_module:
+            calls += [(m, T) for mlp in sa.mlps for m in mlp if isinstance(m, nn.Conv2d)]
+        for d, layer in enumerate(self.flow_module.flow_emb_layers):
+            calls += [(m, T - 1 - d) for m in layer.mlp_convs]
+        calls += [(m, 1) for mlp in self.SA_pooling.mlps for m in mlp if isinstance(m, nn.Conv2d)]
+        calls += [(m, 1) for m in self.fc_layers.modules() if isinstance(m, nn.Linear)]
+        return calls
+
     def _forward(self, pos_lst, cutoff, feat_lst, width):
         if feat_lst is not None:
             assert len(feat_lst) == len(pos_lst)
-        feats, poss = self._levels(pos_lst, feat_lst)               # rows all the way
-        f = self.flow_module.forward_rows(feats, poss, self.flow_radius_scale * cutoff)
-        _, f = self.SA_pooling.forward_rows(poss[0], f)
-        return _head_fp32(self.fc_layers, f.reshape(-1, width))
+        with sn_prefetch(self._sn_calls(len(pos_lst)), self.training):
+            feats, poss = self._levels(pos_lst, feat_lst)           # rows all the way
+            f = self.flow_module.forward_rows(feats, poss, self.flow_radius_scale * cutoff)
+            _, f = self.SA_pooling.forward_rows(poss[0], f)
+            return _head_fp32(self.fc_layers, f.reshape(-1, width))
 
 
 class ActionTempoDis(_TempoDis):
@@ -514,12 +552,20 @@ class FluidTempoDis(_TempoDis):
 
 
 class _SpatialDis(nn.Module):
+    def _sn_calls(self):
+        calls = []
+        for sa in list(self.coarse_graining_module) + [self.SA_pooling]:
+            calls += [(m, 1) for mlp in sa.mlps for m in mlp if isinstance(m, nn.Conv2d)]
+        calls += [(m, 1) for m in self.fc_layers.modules() if isinstance(m, nn.Linear)]
+        return calls
+
     def _forward(self, pos, width):
-        feature = None
-        for sa in self.coarse_graining_module:
-            pos, feature = sa.forward_rows(pos, pos if feature is None else feature)
-        _, feature = self.SA_pooling.forward_rows(pos, feature)
-        return _head_fp32(self.fc_layers, feature.reshape(-1, width))
+        with sn_prefetch(self._sn_calls(), self.training):
+            feature = None
+            for sa in self.coarse_graining_module:
+                pos, feature = sa.forward_rows(pos, pos if feature is None else feature)
+            _, feature = self.SA_pooling.forward_rows(pos, feature)
+            return _head_fp32(self.fc_layers, feature.reshape(-1, width))
 
 
 class ActionSpatialDis(_SpatialDis):

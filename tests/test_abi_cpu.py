@@ -33,7 +33,7 @@ def test_library_exports_every_declared_symbol(hip_lib):
     from tpgan_amd import _lib
     for name in _declared_symbols():
         assert hasattr(hip_lib, name), f"{name} declared in include/ but not exported"
-    assert set(_lib.SIGNATURES) | set(_lib.STRING_GETTERS) | set(_lib.SIZE_GETTERS) == _declared_symbols()
+    assert set(_lib.SIGNATURES) | set(_lib.STRING_GETTERS) | set(_lib.SIZE_GETTERS) | set(_lib.OTHER_GETTERS) == _declared_symbols()
     assert hip_lib.tpg_target_arch() == b"gfx950"
 
 
