@@ -49,15 +49,19 @@ HBM_PEAK_GBPS = 8000.0   # MI355X spec, /opt/skills/guides/MI355X_MICROARCH.md
 OPT = Namespace(use_vel=False, in_node_feats=3, cutoff=0.025, R=0.10, w=0.5)
 
 
-def build(device, seed=1):
+def build(device, seed=1, capturable=False):
     torch.manual_seed(seed)
     G = force_all_keep(SRNet(3, 128)).to(device)
     Ds = FluidSpatialDis().to(device)
     Dt = FluidTempoDis(3).to(device)
     lr = 3e-4
-    opts = (torch.optim.Adam(G.parameters(), lr=lr), torch.optim.Adam(Dt.parameters(), lr=0.33 * lr),
-            torch.optim.Adam(Ds.parameters(), lr=0.33 * lr))
+    kw = {"capturable": True} if capturable else {}
+    opts = (torch.optim.Adam(G.parameters(), lr=lr, **kw), torch.optim.Adam(Dt.parameters(), lr=0.33 * lr, **kw),
+            torch.optim.Adam(Ds.parameters(), lr=0.33 * lr, **kw))
     return G, Ds, Dt, opts
+
+
+GRAPHED = None   # GraphedFluidStep when the hipGraph path is active
 
 
 def run_steps(models, clips, n, sync, amp_dtype, start=0):
@@ -65,8 +69,11 @@ def run_steps(models, clips, n, sync, amp_dtype, start=0):
     out = None
     for i in range(n):
         low, high = clips[(start + i) % len(clips)]
-        out = tempo_gan_step(G, Ds, Dt, low, None, high, None, 1.0, OPT, 12, og, ot, os_,
-                             sync=sync, amp_dtype=amp_dtype, force_gate=True)
+        if GRAPHED is not None and low[0].is_cuda:
+            out = GRAPHED(low, high, 12)
+        else:
+            out = tempo_gan_step(G, Ds, Dt, low, None, high, None, 1.0, OPT, 12, og, ot, os_,
+                                 sync=sync, amp_dtype=amp_dtype, force_gate=True)
     return out
 
 
@@ -98,13 +105,17 @@ def cpu_baseline(sample_batch, per_gpu_batch, n_hi):
 
 
 def roofline_leg(models, clips, steps, sync, amp_dtype):
+    """Per-kernel HIP-event timing needs individual launches: this leg always runs eagerly."""
+    global GRAPHED
     timer = ops.OpTimer()
     ops.set_timer(timer)
+    saved, GRAPHED = GRAPHED, None
     try:
         run_steps(models, clips, steps, sync, amp_dtype)
         torch.cuda.synchronize()
     finally:
         ops.set_timer(None)
+        GRAPHED = saved
     summ = timer.summary()
     name = max(summ, key=lambda k: summ[k]["total_ms"])
     dom = summ[name]
@@ -127,6 +138,8 @@ def main():
     ap.add_argument("--dtype", choices=["bf16", "fp32"], default="bf16")
     ap.add_argument("--no-extra", action="store_true", help="skip roofline and cpu_baseline legs")
     ap.add_argument("--cpu-sample-batch", type=int, default=4)
+    ap.add_argument("--no-graph", action="store_true",
+                    help="run the step eagerly instead of replaying it from captured hipGraphs")
     ap.add_argument("--miopen", action="store_true",
                     help="let PyTorch use MIOpen for conv/BN (first use JIT-compiles per shape: minutes)")
     args = ap.parse_args()
@@ -145,10 +158,22 @@ def main():
     sync = ddp.GradSync()
 
     np.random.seed(1234 + rank)
-    models = build(device)
+    models = build(device, capturable=not args.no_graph)
     sync.broadcast_state(*models[:3])
     clips = [fluid_clip(args.batch, args.points, 8, 3, seed=1234 + rank * 1000 + s, device=device)
              for s in range(4)]
+    global GRAPHED
+    mode = "eager"
+    if not args.no_graph:
+        try:
+            from tpgan_amd.gan_step_graph import GraphedFluidStep
+            G, Ds, Dt, opts = models
+            GRAPHED = GraphedFluidStep(G, Ds, Dt, opts, OPT, clips[0][0], clips[0][1], 1.0, amp_dtype, sync)
+            mode = "hipgraph (%d graph%s per step)" % (len(GRAPHED._graphs[True]), "s" if len(GRAPHED._graphs[True]) > 1 else "")
+        except Exception as e:   # noqa: BLE001 -- never lose the measurement to a capture problem
+            GRAPHED = None
+            log(f"hipGraph capture failed ({type(e).__name__}: {e}); running eagerly")
+    log(f"rank {rank}: step mode = {mode}")
 
     log(f"rank {rank}: models and clips resident, warming up")
     for w in range(args.warmup):
@@ -180,7 +205,7 @@ def main():
                    "value_definition": "batch-of-%d steps per second summed over ranks" % args.batch,
                    "precision": "bf16 autocast on 1x1 convs/linears; coordinates, neighbour search, "
                                 "indices, Chamfer in fp32" if args.dtype == "bf16" else "fp32",
-                   "parallelism": f"dp{world}", "last_losses": last},
+                   "parallelism": f"dp{world}", "step_mode": mode, "last_losses": last},
     }
     if rank == 0 and world == 1 and not args.no_extra:
         roof, table = roofline_leg(models, clips, min(args.steps, 5), sync, amp_dtype)

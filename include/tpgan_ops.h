@@ -171,13 +171,15 @@ int tpg_spectral_norm_bwd(const float *G, const float *Wsn, const float *u, cons
  * its own W / sigma.  For use t the kernel writes at out + out_off + t * stride(R, Cn) floats:
  *   W/sigma_t (R*Cn) | u_t (R) | v_t (Cn) | sigma_t (1),  stride = tpg_spectral_norm_multi_stride.
  * max_rc = max over m of (R + Cn).  u, v are left at their final values.
- * Backward: desc of M records {float* dW; int64 R, Cn, uses, out_off, g_first} (6 x 8 bytes),
- * gptr: device array of gradient pointers (NULL = no gradient for that use), use t of weight m
- * at gptr[g_first + t]; dW[m] = sum_t (G_t - <G_t, Wsn_t> u_t v_t^T) / sigma_t. */
+ * Backward: desc of M records {int64 R, Cn, uses, out_off, g_off, dw_off} (6 x 8 bytes); the
+ * gradient of use t of weight m is at g + g_off + t*R*Cn, and
+ * dw + dw_off <- sum_t (G_t - <G_t, Wsn_t> u_t v_t^T) / sigma_t.  Both descriptor arrays hold
+ * only sizes, offsets and the persistent parameter pointers, so they can be built once. */
 long long tpg_spectral_norm_multi_stride(int R, int Cn);
 int tpg_spectral_norm_multi_fwd(const void *desc, int M, int max_rc, float *out, int iterate, float eps,
                                 void *stream);
-int tpg_spectral_norm_multi_bwd(const void *desc, const void *gptr, int M, const float *out, void *stream);
+int tpg_spectral_norm_multi_bwd(const void *desc, int M, const float *g, const float *out, float *dw,
+                                void *stream);
 
 #ifdef __cplusplus
 }

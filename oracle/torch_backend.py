@@ -119,13 +119,19 @@ class OracleBackend:
 
     def spectral_norm_multi_fwd(self, Ws, us, vs, uses, iterate, eps):
         from tpgan_amd.ops import sn_multi_stride
-        strides = [sn_multi_stride(W.shape[0], W.shape[1]) for W in Ws]
-        offs, total = [], 0
-        for st, n in zip(strides, uses):
-            offs.append(total)
-            total += st * n
-        flat = torch.zeros(total)
-        for W, u, v, n, off, st in zip(Ws, us, vs, uses, offs, strides):
+        layout, goffs, dwoffs = [], [], []
+        out_total = g_total = dw_total = 0
+        for W, n in zip(Ws, uses):
+            R_, Cn = W.shape
+            st = sn_multi_stride(R_, Cn)
+            layout.append((out_total, st))
+            goffs.append(g_total)
+            dwoffs.append(dw_total)
+            out_total += st * n
+            g_total += R_ * Cn * n
+            dw_total += R_ * Cn
+        flat = torch.zeros(out_total)
+        for W, u, v, n, (off, st) in zip(Ws, us, vs, uses, layout):
             R_, Cn = W.shape
             for t in range(n):
                 Wsn, u2, v2, sigma = R.spectral_norm_fwd(_np(W), _np(u), _np(v), iterate, eps)
@@ -137,24 +143,24 @@ class OracleBackend:
                 flat[o + R_ * Cn:o + R_ * Cn + R_] = _t(u2)
                 flat[o + R_ * Cn + R_:o + R_ * Cn + R_ + Cn] = _t(v2)
                 flat[o + R_ * Cn + R_ + Cn] = float(sigma)
-        return flat, list(zip(offs, strides)), None
+        plan = dict(layout=layout, goffs=goffs, dwoffs=dwoffs, dw_total=dw_total,
+                    shapes=[tuple(W.shape) for W in Ws], uses=list(uses))
+        return flat, plan
 
-    def spectral_norm_multi_bwd(self, out, layout, shapes, uses, grads):
-        dWs, gi = [], 0
-        for (R_, Cn), n, (off, st) in zip(shapes, uses, layout):
-            dW = np.zeros((R_, Cn), np.float32)
+    def spectral_norm_multi_bwd(self, out, plan, gflat):
+        dw = torch.zeros(plan["dw_total"])
+        for (R_, Cn), n, (off, st), goff, dwoff in zip(plan["shapes"], plan["uses"], plan["layout"], plan["goffs"],
+                                                       plan["dwoffs"]):
+            acc = np.zeros((R_, Cn), np.float32)
             for t in range(n):
-                g = grads[gi]
-                gi += 1
-                if g is None:
-                    continue
                 o = off + t * st
+                g = _np(gflat[goff + t * R_ * Cn: goff + (t + 1) * R_ * Cn]).reshape(R_, Cn)
                 Wsn = _np(out[o:o + R_ * Cn]).reshape(R_, Cn)
                 u = _np(out[o + R_ * Cn:o + R_ * Cn + R_])
                 v = _np(out[o + R_ * Cn + R_:o + R_ * Cn + R_ + Cn])
-                dW += R.spectral_norm_bwd(_np(g), Wsn, u, v, float(out[o + R_ * Cn + R_ + Cn]))
-            dWs.append(_t(dW))
-        return dWs
+                acc += R.spectral_norm_bwd(g, Wsn, u, v, float(out[o + R_ * Cn + R_ + Cn]))
+            dw[dwoff:dwoff + R_ * Cn] = _t(acc).reshape(-1)
+        return dw
 
 
 def install():

@@ -38,7 +38,7 @@ SIGNATURES = {
     "tpg_spectral_norm_fwd": [_P, _P, _P, _I, _I, _I, _F, _P, _P, _P],
     "tpg_spectral_norm_bwd": [_P, _P, _P, _P, _P, _I, _I, _P, _P],
     "tpg_spectral_norm_multi_fwd": [_P, _I, _I, _P, _I, _F, _P],
-    "tpg_spectral_norm_multi_bwd": [_P, _P, _I, _P, _P],
+    "tpg_spectral_norm_multi_bwd": [_P, _I, _P, _P, _P, _P],
 }
 SIZE_GETTERS = ("tpg_rowbn_workspace_bytes",)
 OTHER_GETTERS = ("tpg_spectral_norm_multi_stride",)

@@ -186,22 +186,25 @@ __global__ __launch_bounds__(SN_THREADS) void spectral_norm_multi_fwd_kernel(con
     }
 }
 
-// gdesc[m*max_uses + t] = pointer to the gradient of use t (or null); dW[m] = sum over uses
+// backward: gradients of all uses are packed in one flat buffer (use t of weight m at
+// g + g_off + t*R*Cn), dW[m] (at dw + dw_off) = sum over uses; descriptors hold only sizes
+// and offsets, so they are built once and stay valid for every later call (and for replay
+// from a captured graph).
 struct SnBwdDesc {
-    float *dW;
-    long long R, Cn, uses, out_off, g_first;
+    long long R, Cn, uses, out_off, g_off, dw_off;
 };
 __global__ __launch_bounds__(SN_THREADS) void spectral_norm_multi_bwd_kernel(const SnBwdDesc *__restrict__ desc,
-                                                                             const float *const *__restrict__ gptr,
-                                                                             const float *__restrict__ out) {
+                                                                             const float *__restrict__ g,
+                                                                             const float *__restrict__ out,
+                                                                             float *__restrict__ dw) {
     __shared__ float scratch[16];
     const SnBwdDesc d = desc[blockIdx.x];
     const int R = (int)d.R, Cn = (int)d.Cn, tid = threadIdx.x;
     const size_t n = (size_t)R * Cn;
-    for (size_t e = tid; e < n; e += SN_THREADS) d.dW[e] = 0.0f;
+    float *dW = dw + d.dw_off;
+    for (size_t e = tid; e < n; e += SN_THREADS) dW[e] = 0.0f;
     for (int t = 0; t < (int)d.uses; ++t) {
-        const float *G = gptr[d.g_first + t];
-        if (!G) continue;  // wave-uniform: this use did not receive a gradient
+        const float *G = g + d.g_off + (size_t)t * n;
         const float *o = out + d.out_off + (size_t)t * sn_stride(R, Cn);
         const float *ou = o + n, *ov = ou + R;
         const float sigma = ov[Cn];
@@ -210,7 +213,7 @@ __global__ __launch_bounds__(SN_THREADS) void spectral_norm_multi_bwd_kernel(con
         dot = block_sum(dot, scratch);
         for (size_t e = tid; e < n; e += SN_THREADS) {
             const int i = (int)(e / Cn), j = (int)(e - (size_t)i * Cn);
-            d.dW[e] += (G[e] - dot * ou[i] * ov[j]) / sigma;
+            dW[e] += (G[e] - dot * ou[i] * ov[j]) / sigma;
         }
     }
 }
@@ -231,12 +234,12 @@ extern "C" int tpg_spectral_norm_multi_fwd(const void *desc, int M, int max_rc, 
     return TPG_OK;
 }
 
-extern "C" int tpg_spectral_norm_multi_bwd(const void *desc, const void *gptr, int M, const float *out,
+extern "C" int tpg_spectral_norm_multi_bwd(const void *desc, int M, const float *g, const float *out, float *dw,
                                            void *stream) {
-    if (M < 0 || !desc || !gptr || !out) return TPG_ERR_ARG;
+    if (M < 0 || !desc || !g || !out || !dw) return TPG_ERR_ARG;
     if (M == 0) return TPG_OK;
     hipLaunchKernelGGL(spectral_norm_multi_bwd_kernel, dim3(M), dim3(SN_THREADS), 0, tpg_stream(stream),
-                       static_cast<const SnBwdDesc *>(desc), static_cast<const float *const *>(gptr), out);
+                       static_cast<const SnBwdDesc *>(desc), g, out, dw);
     TPG_RETURN_IF_LAUNCH_FAILED();
     return TPG_OK;
 }

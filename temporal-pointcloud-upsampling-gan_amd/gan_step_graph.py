@@ -1,0 +1,259 @@
+"""The adversarial step replayed from HIP graphs.
+
+After the kernels were fused the eager step issues ~3400 launches (569 GEMMs at ~23 us of host
+time each) and is bound by the HOST, not by the GPU (rocprof: 41 ms of kernels per 62 ms step).
+`GraphedFluidStep` captures the whole iteration of `gan_step.tempo_gan_step` -- generator and
+both discriminator updates, forward, backward and Adam -- into HIP graphs once and replays them.
+
+Valid only in the STATIC regime of the step, which is checked on the device every replay:
+  * `n_iter > 10` (mask loss active), gate open (`masking_loss < 0.1`),
+  * the generator keeps every slot (no 999 padding => no host-side dummy replacement,
+    discriminator.py:115-130, and shapes are fixed).
+If a replay finds the regime violated, all state (parameters, buffers, optimizer state, RNG) is
+restored from the pre-step snapshot and the step is re-run eagerly with the same random draws,
+so results never depend on which path ran.  `tempo_gan_step_no_mask` has no gate and no mask
+and is always static (`GraphedActionStep` is a "next" item).
+
+Host randomness (noisy labels, label flip, rotation augmentation, point permutations) is drawn
+on the host in the reference's order and fed through static device tensors; "no rotation" is a
+multiplication by the identity matrix, which is exact in fp32, so one graph serves both cases.
+
+Multi-GPU: with `sync.world_size > 1` the step is captured as four graphs and the three flat
+gradient all-reduces run eagerly between them (RCCL calls are kept out of capture).
+"""
+import contextlib
+
+import numpy as np
+import torch
+
+from .gan_step import _frozen, _autocast, _set_dummy_check, _NoSync, get_rotation_matrix, tempo_gan_step
+from .losses import tpugan_sr_loss
+
+
+def _state_tensors(modules, optims):
+    ts = []
+    for m in modules:
+        ts += [p.data for p in m.parameters()] + [b for b in m.buffers()]
+    for o in optims:
+        for st in o.state.values():
+            ts += [v for v in st.values() if torch.is_tensor(v)]
+    return ts
+
+
+class GraphedFluidStep:
+    def __init__(self, sr_net, spatial_dis, tempo_dis, optims, opt, lowres_pos_lst, highres_pos_lst,
+                 furthest_distance=1.0, amp_dtype=None, sync=None, warmup=2, segmented=None):
+        self.G, self.Ds, self.Dt = sr_net, spatial_dis, tempo_dis
+        self.og, self.ot, self.os = optims
+        for o in optims:
+            if not all(g.get("capturable", False) for g in o.param_groups):
+                raise ValueError("graph capture needs optimizers built with capturable=True")
+        self.opt, self.fd, self.amp = opt, furthest_distance, amp_dtype
+        self.sync = sync or _NoSync()
+        self.segmented = (self.sync.world_size > 1) if segmented is None else segmented
+        dev = lowres_pos_lst[0].device
+        self.dev, self.T, self.B = dev, len(highres_pos_lst), lowres_pos_lst[0].shape[0]
+        self.low = [torch.empty_like(x) for x in lowres_pos_lst]
+        self.high = [torch.empty_like(x) for x in highres_pos_lst]
+        n_pred = lowres_pos_lst[0].shape[1] * sr_net.upsample_ratio
+        self.lab = torch.zeros(4, device=dev)
+        self.perm_c = torch.arange(n_pred, device=dev)
+        self.perm_f = [torch.arange(n_pred, device=dev) for _ in range(self.T - 1)]
+        eye = torch.eye(3, device=dev)
+        self.rot_fake_t = eye.repeat(self.T, 1, 1)
+        self.rot_true_t = eye.repeat(self.T, 1, 1)
+        self.rot_fake_s = eye.repeat(self.B, 1, 1)
+        self.rot_true_s = eye.repeat(self.B, 1, 1)
+        self.report = torch.zeros(6, device=dev)
+        self.viol = torch.zeros(1, device=dev)
+        self._keep = {}
+        self._graphs = None
+        self._capture(lowres_pos_lst, highres_pos_lst, warmup)
+
+    # ------------------------------------------------------------------ step body (capturable)
+    def _seg_generator(self):
+        G, Ds, Dt, opt, k = self.G, self.Ds, self.Dt, self.opt, self._keep
+        low, high, lab = self.low, self.high, self.lab
+        others = [0] + list(range(2, self.T))
+        with _autocast(self.amp, self.dev):
+            edge, mask = G.body(low[1], low[1])
+        pred_c, padded_c, keep_c = G.expand_pos_static(low[1], edge, mask)
+        position_loss, cd, ml = tpugan_sr_loss(100., high[1], pred_c.float(), low[1], mask.float(),
+                                               opt.cutoff / self.fd, 11)
+        viol = (ml.reshape(()) >= 0.1) | ~keep_c
+        _set_dummy_check(Ds, False)
+        _set_dummy_check(Dt, False)
+        with _frozen(Ds, Dt), _autocast(self.amp, self.dev):
+            fake = Ds(padded_c.index_select(1, self.perm_c).float())
+            spatial_loss = (0.5 * (fake.float() - lab[2]) ** 2).mean()
+            edge_o, mask_o = G.body(torch.cat([low[f] for f in others], 0), torch.cat([low[f] for f in others], 0))
+            pred_lst = [None] * self.T
+            pred_lst[1] = padded_c
+            for i, f in enumerate(others):
+                sl = slice(i * self.B, (i + 1) * self.B)
+                _, padded, keep = G.expand_pos_static(low[f], edge_o[sl], mask_o[sl])
+                viol = viol | ~keep
+                pred_lst[f] = padded.index_select(1, self.perm_f[i])
+                last_padded = padded
+            fake = Dt([p.float() for p in pred_lst], opt.R)
+            tempo_loss = (0.5 * (fake.float() - lab[3]) ** 2).mean()
+        sr_loss = tempo_loss + spatial_loss + opt.w * position_loss
+        self.og.zero_grad(set_to_none=True)
+        sr_loss.backward()
+        k.update(pred_lst=[p.detach() for p in pred_lst], last_padded=last_padded.detach(), tempo_loss=tempo_loss.detach(),
+                 spatial_loss=spatial_loss.detach(), cd=cd.detach(), ml=ml.detach())
+        self.viol.copy_(viol.float().reshape(1))
+
+    def _seg_tempo(self, update_D):
+        self.og.step()
+        k, lab = self._keep, self.lab
+        if not update_D:
+            k["tempo_dis_loss"] = torch.zeros((), device=self.dev)
+            return
+        fakes = [torch.matmul(p.float(), self.rot_fake_t[f]) for f, p in enumerate(k["pred_lst"])]
+        trues = [torch.matmul(h, self.rot_true_t[f]) for f, h in enumerate(self.high)]
+        with _autocast(self.amp, self.dev):
+            fake = self.Dt(fakes, self.opt.R)
+            true = self.Dt(trues, self.opt.R)
+        loss = (0.5 * ((true.float() - lab[0]) ** 2 + (fake.float() - lab[1]) ** 2)).mean()
+        self.ot.zero_grad(set_to_none=True)
+        loss.backward()
+        k["tempo_dis_loss"] = loss.detach()
+
+    def _seg_spatial(self, update_D):
+        k, lab = self._keep, self.lab
+        if not update_D:
+            k["spatial_dis_loss"] = torch.zeros((), device=self.dev)
+            return
+        self.ot.step()
+        fake_cloud = torch.bmm(k["last_padded"].float(), self.rot_fake_s)
+        true_cloud = torch.bmm(self.high[1], self.rot_true_s)
+        with _autocast(self.amp, self.dev):
+            fake = self.Ds(fake_cloud)
+            true = self.Ds(true_cloud)
+        loss = (0.5 * ((true.float() - lab[0]) ** 2 + (fake.float() - lab[1]) ** 2)).mean()
+        self.os.zero_grad(set_to_none=True)
+        loss.backward()
+        k["spatial_dis_loss"] = loss.detach()
+
+    def _seg_finish(self, update_D):
+        if update_D:
+            self.os.step()
+        k = self._keep
+        self.report.copy_(torch.stack([k["tempo_loss"].reshape(()), k["tempo_dis_loss"].reshape(()),
+                                       k["cd"].reshape(()), k["ml"].reshape(()),
+                                       k["spatial_loss"].reshape(()), k["spatial_dis_loss"].reshape(())]).float())
+
+    def _segments(self, update_D):
+        return [("G", self._seg_generator, self.G), ("Dt", lambda: self._seg_tempo(update_D), self.Dt if update_D else None),
+                ("Ds", lambda: self._seg_spatial(update_D), self.Ds if update_D else None),
+                ("end", lambda: self._seg_finish(update_D), None)]
+
+    def _run_eager(self, update_D):
+        for _, fn, reduce_module in self._segments(update_D):
+            fn()
+            if reduce_module is not None:
+                self.sync.average_grads(reduce_module)
+
+    # ------------------------------------------------------------------ capture
+    def _load(self, low, high):
+        for d, s in zip(self.low, low):
+            d.copy_(s)
+        for d, s in zip(self.high, high):
+            d.copy_(s)
+
+    def _capture(self, low, high, warmup):
+        modules, optims = (self.G, self.Ds, self.Dt), (self.og, self.ot, self.os)
+        before = _state_tensors(modules, optims)
+        snap = [t.clone() for t in before]
+        known = {t.data_ptr() for t in before}
+        rng = torch.cuda.get_rng_state(self.dev)
+        self._load(low, high)
+        self.lab.copy_(torch.tensor([1.0, 0.1, 1.0, 1.0]))
+        torch.cuda.synchronize(self.dev)
+        side = torch.cuda.Stream(self.dev)
+        side.wait_stream(torch.cuda.current_stream(self.dev))
+        with torch.cuda.stream(side):
+            for _ in range(max(1, warmup)):       # real steps on the example batch; undone below
+                self._run_eager(True)
+        torch.cuda.current_stream(self.dev).wait_stream(side)
+        torch.cuda.synchronize(self.dev)
+        # undo the warm-up: parameters / buffers / pre-existing optimizer state from the snapshot,
+        # optimizer state created by the warm-up back to zero (= a fresh optimizer)
+        torch._foreach_copy_(before, snap)
+        for t in _state_tensors(modules, optims):
+            if t.data_ptr() not in known:
+                t.zero_()
+        torch.cuda.set_rng_state(rng, self.dev)
+        self._graphs = {}
+        for update_D in (True, False):
+            graphs, pool = [], None
+            segs = self._segments(update_D)
+            if not self.segmented:
+                segs = [("all", lambda segs=segs: [fn() for _, fn, _ in segs], None)]
+            for name, fn, reduce_module in segs:
+                g = torch.cuda.CUDAGraph()
+                with torch.cuda.graph(g, pool=pool):
+                    fn()
+                pool = g.pool()
+                graphs.append((g, reduce_module))
+            self._graphs[update_D] = graphs
+            self._keep_alive = getattr(self, "_keep_alive", []) + [dict(self._keep)]
+        self._state = _state_tensors(modules, optims)
+        self._snap = [torch.empty_like(t) for t in self._state]
+        torch.cuda.synchronize(self.dev)
+
+    # ------------------------------------------------------------------ one training step
+    def __call__(self, lowres_pos_lst, highres_pos_lst, n_iter, freeze_D=False):
+        """Same contract as gan_step.tempo_gan_step (without velocities); returns its loss dict."""
+        update_D = n_iter % 2 == 0 and not freeze_D
+        if n_iter <= 10:
+            return self._eager(lowres_pos_lst, highres_pos_lst, n_iter, freeze_D)
+        np_state, cpu_rng = np.random.get_state(), torch.get_rng_state()
+        cuda_rng = torch.cuda.get_rng_state(self.dev)
+        # host draws, in the reference's order (train_step_final.py:85-90,121,152,171-204)
+        valid, invalid = np.random.uniform(0.8, 1.2), np.random.uniform(0.0, 0.2)
+        if np.random.uniform(0.0, 1.0) < 0.03:
+            valid, invalid = invalid, valid
+        lab_s, lab_t = np.random.uniform(0.8, 1.2), np.random.uniform(0.8, 1.2)
+        n_pred = self.perm_c.numel()
+        perms = [torch.randperm(n_pred) for _ in range(self.T)]
+        eye = torch.eye(3)
+        rft, rtt = [eye] * self.T, [eye] * self.T
+        rfs, rts = [eye] * self.B, [eye] * self.B
+        if update_D:
+            if np.random.uniform() > 0.7:
+                rft = [get_rotation_matrix() for _ in range(self.T)]
+                rtt = [get_rotation_matrix() for _ in range(self.T)]
+            if np.random.uniform() > 0.7:
+                rts = [get_rotation_matrix() for _ in range(self.B)]
+                rfs = [get_rotation_matrix() for _ in range(self.B)]
+        self._load(lowres_pos_lst, highres_pos_lst)
+        self.lab.copy_(torch.tensor([valid, invalid, lab_s, lab_t], dtype=torch.float32), non_blocking=True)
+        self.perm_c.copy_(perms[0], non_blocking=True)
+        for d, s in zip(self.perm_f, perms[1:]):
+            d.copy_(s, non_blocking=True)
+        self.rot_fake_t.copy_(torch.stack(rft), non_blocking=True)
+        self.rot_true_t.copy_(torch.stack(rtt), non_blocking=True)
+        self.rot_fake_s.copy_(torch.stack(rfs), non_blocking=True)
+        self.rot_true_s.copy_(torch.stack(rts), non_blocking=True)
+        torch._foreach_copy_(self._snap, self._state)                 # pre-step snapshot (18 MB)
+        for g, reduce_module in self._graphs[update_D]:
+            g.replay()
+            if reduce_module is not None:
+                self.sync.average_grads(reduce_module)
+        out = torch.cat([self.report, self.viol]).cpu().tolist()        # the step's one host sync
+        if out[6] != 0.0:
+            # not the static regime: put everything back and take the general path with the same draws
+            torch._foreach_copy_(self._state, self._snap)
+            np.random.set_state(np_state)
+            torch.set_rng_state(cpu_rng)
+            torch.cuda.set_rng_state(cuda_rng, self.dev)
+            return self._eager(lowres_pos_lst, highres_pos_lst, n_iter, freeze_D)
+        keys = ["tempo_G_loss", "tempo_D_loss", "Chamfer_distance_no_norm", "masking_loss", "spatial_G_loss",
+                "spatial_D_loss"]
+        return dict(zip(keys, out[:6]))
+
+    def _eager(self, low, high, n_iter, freeze_D):
+        return tempo_gan_step(self.G, self.Ds, self.Dt, low, None, high, None, self.fd, self.opt, n_iter, self.og,
+                              self.ot, self.os, freeze_D, sync=self.sync, amp_dtype=self.amp)

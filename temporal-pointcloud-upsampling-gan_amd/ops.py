@@ -119,6 +119,7 @@ class HipBackend:
     def __init__(self):
         self.lib = _lib.load()
         self._ws = {}
+        self._sn_plans = {}
 
     def _call(self, symbol, op, nbytes, ref, *args):
         fn = getattr(self.lib, symbol)
@@ -314,40 +315,47 @@ class HipBackend:
         return dW
 
 
+    def _sn_plan(self, Ws, us, vs, uses):
+        """Static description of a batched spectral-norm call (cached per parameter set): device
+        descriptor arrays for forward and backward + buffer layouts.  Nothing in it depends on a
+        per-call allocation, so no host->device copy happens after the first call (capture-safe)."""
+        key = tuple(t.data_ptr() for t in (*Ws, *us, *vs)) + tuple(uses)
+        plan = self._sn_plans.get(key)
+        if plan is None:
+            dev = Ws[0].device
+            fwd, bwd, layout, goffs, dwoffs = [], [], [], [], []
+            out_total = g_total = dw_total = 0
+            for W, u, v, n in zip(Ws, us, vs, uses):
+                R, Cn = W.shape
+                st = sn_multi_stride(R, Cn)
+                fwd += [W.data_ptr(), u.data_ptr(), v.data_ptr(), R, Cn, n, out_total]
+                bwd += [R, Cn, n, out_total, g_total, dw_total]
+                layout.append((out_total, st))
+                goffs.append(g_total)
+                dwoffs.append(dw_total)
+                out_total += st * n
+                g_total += R * Cn * n
+                dw_total += R * Cn
+            plan = dict(fwd=torch.tensor(fwd, dtype=torch.int64).to(dev), bwd=torch.tensor(bwd, dtype=torch.int64).to(dev),
+                        layout=layout, goffs=goffs, dwoffs=dwoffs, out_total=out_total, g_total=g_total,
+                        dw_total=dw_total, max_rc=max(W.shape[0] + W.shape[1] for W in Ws), M=len(Ws))
+            self._sn_plans[key] = plan
+        return plan
+
     def spectral_norm_multi_fwd(self, Ws, us, vs, uses, iterate, eps):
-        """-> (flat buffer, [(offset, stride)] per weight); layout in include/tpgan_ops.h."""
-        dev = Ws[0].device
-        strides = [sn_multi_stride(W.shape[0], W.shape[1]) for W in Ws]
-        offs, total = [], 0
-        for st, n in zip(strides, uses):
-            offs.append(total)
-            total += st * n
-        rec = []
-        for W, u, v, n, off in zip(Ws, us, vs, uses, offs):
-            rec += [W.data_ptr(), u.data_ptr(), v.data_ptr(), W.shape[0], W.shape[1], n, off]
-        desc = torch.tensor(rec, dtype=torch.int64).to(dev, non_blocking=True)
-        out = torch.empty(total, dtype=torch.float32, device=dev)
-        max_rc = max(W.shape[0] + W.shape[1] for W in Ws)
+        """-> (flat output buffer, plan); output layout in include/tpgan_ops.h."""
+        plan = self._sn_plan(Ws, us, vs, uses)
+        out = torch.empty(plan["out_total"], dtype=torch.float32, device=Ws[0].device)
         nbytes = 4 * sum((1 + n) * W.numel() for W, n in zip(Ws, uses))
         self._call("tpg_spectral_norm_multi_fwd", "spectral_norm_fwd", nbytes, out,
-                   _ptr(desc), len(Ws), max_rc, _ptr(out), int(iterate), float(eps))
-        return out, list(zip(offs, strides)), desc
+                   _ptr(plan["fwd"]), plan["M"], plan["max_rc"], _ptr(out), int(iterate), float(eps))
+        return out, plan
 
-    def spectral_norm_multi_bwd(self, out, layout, shapes, uses, grads):
-        dev = out.device
-        dWs = [torch.empty(shp, dtype=torch.float32, device=dev) for shp in shapes]
-        rec, gp, first = [], [], 0
-        for dW, shp, n, (off, _st) in zip(dWs, shapes, uses, layout):
-            rec += [dW.data_ptr(), shp[0], shp[1], n, off, first]
-            first += n
-        for g in grads:
-            gp.append(0 if g is None else g.data_ptr())
-        desc = torch.tensor(rec, dtype=torch.int64).to(dev, non_blocking=True)
-        gptr = torch.tensor(gp, dtype=torch.int64).to(dev, non_blocking=True)
-        nbytes = 4 * sum((1 + 2 * n) * shp[0] * shp[1] for shp, n in zip(shapes, uses))
-        self._call("tpg_spectral_norm_multi_bwd", "spectral_norm_bwd", nbytes, out,
-                   _ptr(desc), _ptr(gptr), len(shapes), _ptr(out))
-        return dWs
+    def spectral_norm_multi_bwd(self, out, plan, gflat):
+        dw = torch.empty(plan["dw_total"], dtype=torch.float32, device=out.device)
+        self._call("tpg_spectral_norm_multi_bwd", "spectral_norm_bwd", 4 * (2 * plan["g_total"] + plan["dw_total"]),
+                   out, _ptr(plan["bwd"]), plan["M"], _ptr(gflat), _ptr(out), _ptr(dw))
+        return dw
 
 
 def sn_multi_stride(R, Cn):
@@ -719,21 +727,29 @@ class _SpectralNormMulti(torch.autograd.Function):
     def forward(ctx, training, eps, uses, *tensors):
         n = len(uses)
         Ws, us, vs = tensors[:n], tensors[n:2 * n], tensors[2 * n:]
-        be = backend_for(Ws[0])
-        flat, layout, _ = be.spectral_norm_multi_fwd(list(Ws), list(us), list(vs), list(uses), training, eps)
+        flat, plan = backend_for(Ws[0]).spectral_norm_multi_fwd(list(Ws), list(us), list(vs), list(uses),
+                                                                training, eps)
         outs = []
-        for W, (off, st), k in zip(Ws, layout, uses):
+        for W, (off, st), k in zip(Ws, plan["layout"], uses):
             R, Cn = W.shape
             for t in range(k):
                 outs.append(flat[off + t * st: off + t * st + R * Cn].view(R, Cn))
-        ctx.flat, ctx.layout, ctx.uses = flat, layout, tuple(uses)
+        ctx.flat, ctx.plan, ctx.uses = flat, plan, tuple(uses)
         ctx.shapes = [tuple(W.shape) for W in Ws]
         return tuple(outs)
 
     @staticmethod
     def backward(ctx, *grads):
-        gs = [None if g is None else g.float().contiguous() for g in grads]
-        dWs = backend_for(ctx.flat).spectral_norm_multi_bwd(ctx.flat, ctx.layout, ctx.shapes, ctx.uses, gs)
+        parts, i = [], 0
+        for (R, Cn), k in zip(ctx.shapes, ctx.uses):
+            for _ in range(k):
+                g = grads[i]
+                i += 1
+                parts.append(torch.zeros(R * Cn, dtype=torch.float32, device=ctx.flat.device) if g is None
+                             else g.reshape(-1).float())
+        gflat = torch.cat(parts)
+        dw = backend_for(ctx.flat).spectral_norm_multi_bwd(ctx.flat, ctx.plan, gflat)
+        dWs = [dw[off:off + R * Cn].view(R, Cn) for (R, Cn), off in zip(ctx.shapes, ctx.plan["dwoffs"])]
         n = len(ctx.uses)
         return (None, None, None) + tuple(dWs) + (None,) * (2 * n)
 

@@ -165,6 +165,22 @@ class SRNet(nn.Module):
             return expanded, padded
         return expanded, expanded[hard].view(B, -1, 3)
 
+    def expand_pos_static(self, pos, upsample_edge, binary_mask):
+        """Hard masking without a host decision (for hipGraph capture): always the padded form
+        `where(hard, expanded, 999)`, plus a device flag `all_keep`.  When every slot survives
+        (`all_keep`), this IS what `expand_pos_with_masking(hard_masking=True)` returns; otherwise
+        the caller must not use the static path (dummy handling needs the host)."""
+        B = pos.shape[0]
+        r = self.upsample_ratio
+        keep = binary_mask.detach().view(B, -1, 1) > self.epsilon
+        edge = upsample_edge * keep.float()
+        expanded = pos.repeat(1, 1, r).view(B, -1, 3) + edge.view(B, -1, 3)
+        hard = keep.repeat(1, 1, r)
+        hard[:, :, 0] = True
+        hard = hard.view(B, -1, 1)
+        padded = torch.where(hard, expanded, torch.full_like(expanded, 999.0))
+        return expanded, padded, hard.all()
+
     def forward(self, feature, pos, hard_masking=False):
         edge, mask = self.body(feature, pos)
         out_pos, padded = self.expand_pos_with_masking(pos, edge, mask, hard_masking=hard_masking)

@@ -1,0 +1,83 @@
+"""The hipGraph-replayed step against the eager step: same initial state, same host draws."""
+import copy
+from argparse import Namespace
+
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+OPT = Namespace(use_vel=False, in_node_feats=3, cutoff=0.025, R=0.10, w=0.5)
+
+
+def _build(dev):
+    from tpgan_amd.set_abstraction import FluidSpatialDis, FluidTempoDis
+    from tpgan_amd.srnet import SRNet
+    from tpgan_amd.synthetic import force_all_keep
+    torch.manual_seed(3)
+    G = force_all_keep(SRNet(3, 128)).to(dev)
+    Ds, Dt = FluidSpatialDis().to(dev), FluidTempoDis(3).to(dev)
+    for m in list(Ds.modules()) + list(Dt.modules()):
+        if isinstance(m, torch.nn.Dropout):
+            m.p = 0.0                           # dropout draws differ between eager and replay
+    return G, Ds, Dt
+
+
+def _optims(G, Ds, Dt):
+    kw = dict(lr=3e-4, capturable=True)
+    return (torch.optim.Adam(G.parameters(), **kw), torch.optim.Adam(Dt.parameters(), **kw),
+            torch.optim.Adam(Ds.parameters(), **kw))
+
+
+@pytest.mark.parametrize("segmented", [False, True])
+def test_graph_replay_equals_eager(segmented):
+    from tpgan_amd.gan_step import tempo_gan_step
+    from tpgan_amd.gan_step_graph import GraphedFluidStep
+    from tpgan_amd.synthetic import fluid_clip
+    dev = torch.device("cuda", 0)
+    A = _build(dev)
+    Bm = copy.deepcopy(A)
+    oa, ob = _optims(*A), _optims(*Bm)
+    clips = [fluid_clip(2, 1024, 8, 3, seed=s, device=dev) for s in (1, 2)]
+    stepper = GraphedFluidStep(Bm[0], Bm[1], Bm[2], ob, OPT, clips[0][0], clips[0][1], 1.0, None, None,
+                               segmented=segmented)
+    # capture must leave the model untouched
+    for pa, pb in zip(A[0].parameters(), Bm[0].parameters()):
+        assert torch.equal(pa, pb)
+    for it, (low, high) in zip((12, 13, 14), (clips[0], clips[1], clips[0])):
+        np.random.seed(100 + it); torch.manual_seed(100 + it)
+        le = tempo_gan_step(A[0], A[1], A[2], low, None, high, None, 1.0, OPT, it, oa[0], oa[1], oa[2])
+        np.random.seed(100 + it); torch.manual_seed(100 + it)
+        lg = stepper(low, high, it)
+        assert set(le) == set(lg)
+        for k in le:
+            assert abs(le[k] - lg[k]) <= 2e-3 * max(1.0, abs(le[k])), (it, k, le[k], lg[k])
+    for ma, mb in zip(A, Bm):
+        for (n, pa), (_, pb) in zip(ma.named_parameters(), mb.named_parameters()):
+            rel = float((pa - pb).norm() / pa.norm().clamp_min(1e-6))
+            assert rel <= 2e-3, (n, rel)
+
+
+def test_violation_falls_back_to_eager_with_identical_result():
+    """An untrained mask head closes the gate: the replay detects it, restores every tensor and
+    the step is re-run eagerly -- bit-identical to never having used the graph path."""
+    from tpgan_amd.gan_step import tempo_gan_step
+    from tpgan_amd.gan_step_graph import GraphedFluidStep
+    from tpgan_amd.synthetic import fluid_clip
+    dev = torch.device("cuda", 0)
+    A = _build(dev)
+    Bm = copy.deepcopy(A)
+    oa, ob = _optims(*A), _optims(*Bm)
+    low, high = fluid_clip(2, 1024, 8, 3, seed=1, device=dev)
+    stepper = GraphedFluidStep(Bm[0], Bm[1], Bm[2], ob, OPT, low, high, 1.0, None, None)
+    for m in (A[0], Bm[0]):                                   # drop every point: mask == 0
+        with torch.no_grad():
+            m.filter_block.decoder[1].bias.fill_(-1.0)
+    np.random.seed(5); torch.manual_seed(5)
+    le = tempo_gan_step(A[0], A[1], A[2], low, None, high, None, 1.0, OPT, 12, oa[0], oa[1], oa[2])
+    np.random.seed(5); torch.manual_seed(5)
+    lg = stepper(low, high, 12)
+    assert le == lg and le["tempo_G_loss"] == 0.0
+    for ma, mb in zip(A, Bm):
+        for pa, pb in zip(ma.state_dict().values(), mb.state_dict().values()):
+            assert torch.equal(pa, pb)

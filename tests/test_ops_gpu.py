@@ -411,9 +411,9 @@ def test_spectral_norm_multi_matches_chained_single_calls(hip):
     us = [torch.nn.functional.normalize(torch.randn(s[0], device="cuda"), dim=0) for s in shapes]
     vs = [torch.nn.functional.normalize(torch.randn(s[1], device="cuda"), dim=0) for s in shapes]
     u1, v1 = [u.clone() for u in us], [v.clone() for v in vs]
-    flat, layout, _ = hip.spectral_norm_multi_fwd(Ws, us, vs, uses, True, 1e-12)
+    flat, plan = hip.spectral_norm_multi_fwd(Ws, us, vs, uses, True, 1e-12)
     grads, singles = [], []
-    for W, u, v, n, (off, st) in zip(Ws, u1, v1, uses, layout):
+    for W, u, v, n, (off, st) in zip(Ws, u1, v1, uses, plan["layout"]):
         R_, Cn = W.shape
         for t in range(n):
             Wsn, sigma = hip.spectral_norm_fwd(W, u, v, True, 1e-12)
@@ -421,17 +421,16 @@ def test_spectral_norm_multi_matches_chained_single_calls(hip):
             assert torch.allclose(got, Wsn, rtol=1e-5, atol=1e-6)
             assert abs(float(flat[off + t * st + R_ * Cn + R_ + Cn]) - float(sigma)) <= 1e-5 * float(sigma)
             g = torch.randn_like(Wsn)
-            grads.append(g if (t + R_) % 3 else None)      # some uses receive no gradient
+            grads.append(g)
             singles.append((g, Wsn, u.clone(), v.clone(), sigma))
     for a, b in zip(us + vs, u1 + v1):
         assert torch.allclose(a, b, atol=1e-6)
-    dWs = hip.spectral_norm_multi_bwd(flat, layout, shapes, uses, grads)
+    dw = hip.spectral_norm_multi_bwd(flat, plan, torch.cat([g.reshape(-1) for g in grads]))
     i = 0
-    for dW, n in zip(dWs, uses):
-        ref = torch.zeros_like(dW)
+    for (R_, Cn), n, off in zip(shapes, uses, plan["dwoffs"]):
+        ref = torch.zeros(R_, Cn, device="cuda")
         for t in range(n):
             g, Wsn, u, v, sigma = singles[i]
-            if grads[i] is not None:
-                ref += hip.spectral_norm_bwd(g, Wsn, u, v, sigma)
+            ref += hip.spectral_norm_bwd(g, Wsn, u, v, sigma)
             i += 1
-        assert torch.allclose(dW, ref, rtol=1e-4, atol=1e-5)
+        assert torch.allclose(dw[off:off + R_ * Cn].view(R_, Cn), ref, rtol=1e-4, atol=1e-5)
