@@ -62,6 +62,7 @@ def build(device, seed=1, capturable=False):
 
 
 GRAPHED = None   # GraphedFluidStep when the hipGraph path is active
+TRACE = bool(os.environ.get("TPGAN_BENCH_TRACE"))
 
 
 def run_steps(models, clips, n, sync, amp_dtype, start=0):
@@ -74,6 +75,8 @@ def run_steps(models, clips, n, sync, amp_dtype, start=0):
         else:
             out = tempo_gan_step(G, Ds, Dt, low, None, high, None, 1.0, OPT, 12, og, ot, os_,
                                  sync=sync, amp_dtype=amp_dtype, force_gate=True)
+        if TRACE:
+            log("step %d: %s" % (start + i, {k: round(v, 4) for k, v in out.items()}))
     return out
 
 

@@ -18,6 +18,14 @@ Host randomness (noisy labels, label flip, rotation augmentation, point permutat
 on the host in the reference's order and fed through static device tensors; "no rotation" is a
 multiplication by the identity matrix, which is exact in fp32, so one graph serves both cases.
 
+Index work off the critical path: furthest-point sampling is a chain of npoint-1 dependent
+rounds on B workgroups (0.73 ms per 4096->1024 call, six of them per step), i.e. latency on a
+handful of the 256 CUs.  Every discriminator forward needs its FPS / ball-query / kNN indices,
+and those depend on coordinates only, so each forward's `index_plan` is issued on a side stream
+as soon as its input clouds exist (the real clouds at the very start of the step) and joined
+right before use: inside the captured graph the chains become parallel branches that overlap
+with the generator and discriminator GEMMs.
+
 Multi-GPU: with `sync.world_size > 1` the step is captured as four graphs and the three flat
 gradient all-reduces run eagerly between them (RCCL calls are kept out of capture).
 """
@@ -28,6 +36,7 @@ import torch
 
 from .gan_step import _frozen, _autocast, _set_dummy_check, _NoSync, get_rotation_matrix, tempo_gan_step
 from .losses import tpugan_sr_loss
+from .set_abstraction import run_index_plan
 
 
 def _state_tensors(modules, optims):
@@ -56,36 +65,67 @@ class GraphedFluidStep:
         self.low = [torch.empty_like(x) for x in lowres_pos_lst]
         self.high = [torch.empty_like(x) for x in highres_pos_lst]
         n_pred = lowres_pos_lst[0].shape[1] * sr_net.upsample_ratio
-        self.lab = torch.zeros(4, device=dev)
-        self.perm_c = torch.arange(n_pred, device=dev)
-        self.perm_f = [torch.arange(n_pred, device=dev) for _ in range(self.T - 1)]
-        eye = torch.eye(3, device=dev)
-        self.rot_fake_t = eye.repeat(self.T, 1, 1)
-        self.rot_true_t = eye.repeat(self.T, 1, 1)
-        self.rot_fake_s = eye.repeat(self.B, 1, 1)
-        self.rot_true_s = eye.repeat(self.B, 1, 1)
+        T, B = self.T, self.B
+        # host-drawn inputs of a step travel through ONE persistent pinned staging buffer per dtype
+        # (an async copy from a temporary pageable tensor may read freed memory on HIP)
+        nf = 4 + 9 * (2 * T + 2 * B)
+        self._host_f = torch.zeros(nf, dtype=torch.float32).pin_memory()
+        self._host_i = torch.zeros(T * n_pred, dtype=torch.int64).pin_memory()
+        self._dev_f = torch.zeros(nf, dtype=torch.float32, device=dev)
+        self._dev_i = torch.arange(n_pred, device=dev).repeat(T).contiguous()
+        f = self._dev_f
+        self.lab = f[:4]
+        o = 4
+        self.rot_fake_t = f[o:o + 9 * T].view(T, 3, 3); o += 9 * T
+        self.rot_true_t = f[o:o + 9 * T].view(T, 3, 3); o += 9 * T
+        self.rot_fake_s = f[o:o + 9 * B].view(B, 3, 3); o += 9 * B
+        self.rot_true_s = f[o:o + 9 * B].view(B, 3, 3)
+        self.perm_c = self._dev_i[:n_pred]
+        self.perm_f = [self._dev_i[(i + 1) * n_pred:(i + 2) * n_pred] for i in range(T - 1)]
+        eye = torch.eye(3).reshape(-1)
+        self._host_f[4:] = eye.repeat(2 * T + 2 * B)
+        self._host_f[:4] = torch.tensor([1.0, 0.1, 1.0, 1.0])
+        self._dev_f.copy_(self._host_f)
         self.report = torch.zeros(6, device=dev)
         self.viol = torch.zeros(1, device=dev)
+        self.side = torch.cuda.Stream(dev)
+        self.use_plans = True
         self._keep = {}
         self._graphs = None
         self._capture(lowres_pos_lst, highres_pos_lst, warmup)
 
     # ------------------------------------------------------------------ step body (capturable)
-    def _seg_generator(self):
+    def _plan(self, make):
+        """(plan, join) for a discriminator forward; inline (plan None) when plans are disabled."""
+        if not self.use_plans:
+            return None, (lambda: None)
+        return run_index_plan(make, self.side)
+
+    def _seg_generator(self, update_D):
         G, Ds, Dt, opt, k = self.G, self.Ds, self.Dt, self.opt, self._keep
         low, high, lab = self.low, self.high, self.lab
         others = [0] + list(range(2, self.T))
+        _set_dummy_check(Ds, False)
+        _set_dummy_check(Dt, False)
+        if update_D:
+            # the real clouds exist already: their (rotated) copies and index plans start now
+            def real_side():
+                trues = [torch.matmul(h, self.rot_true_t[f]) for f, h in enumerate(high)]
+                true_s = torch.bmm(high[1], self.rot_true_s)
+                if not self.use_plans:
+                    return trues, true_s, None, None
+                return trues, true_s, Dt.index_plan(trues, opt.R), Ds.index_plan(true_s)
+            (k["trues"], k["true_s"], k["plan_true_t"], k["plan_true_s"]), k["join_real"] = \
+                run_index_plan(real_side, self.side)
         with _autocast(self.amp, self.dev):
             edge, mask = G.body(low[1], low[1])
         pred_c, padded_c, keep_c = G.expand_pos_static(low[1], edge, mask)
+        fake_s_in = padded_c.index_select(1, self.perm_c).float()
+        plan_fs, join_fs = self._plan(lambda: Ds.index_plan(fake_s_in))     # overlaps the other frames
         position_loss, cd, ml = tpugan_sr_loss(100., high[1], pred_c.float(), low[1], mask.float(),
                                                opt.cutoff / self.fd, 11)
-        viol = (ml.reshape(()) >= 0.1) | ~keep_c
-        _set_dummy_check(Ds, False)
-        _set_dummy_check(Dt, False)
+        viol = ~(ml.reshape(()) < 0.1) | ~keep_c                   # NaN counts as a violation
         with _frozen(Ds, Dt), _autocast(self.amp, self.dev):
-            fake = Ds(padded_c.index_select(1, self.perm_c).float())
-            spatial_loss = (0.5 * (fake.float() - lab[2]) ** 2).mean()
             edge_o, mask_o = G.body(torch.cat([low[f] for f in others], 0), torch.cat([low[f] for f in others], 0))
             pred_lst = [None] * self.T
             pred_lst[1] = padded_c
@@ -95,14 +135,30 @@ class GraphedFluidStep:
                 viol = viol | ~keep
                 pred_lst[f] = padded.index_select(1, self.perm_f[i])
                 last_padded = padded
-            fake = Dt([p.float() for p in pred_lst], opt.R)
+            fake_t_in = [p.float() for p in pred_lst]
+            plan_ft, join_ft = self._plan(lambda: Dt.index_plan(fake_t_in, opt.R))   # overlaps D_spatial
+            if update_D:
+                def fake_side():
+                    fakes = [torch.matmul(p.detach(), self.rot_fake_t[f]) for f, p in enumerate(fake_t_in)]
+                    fake_s = torch.bmm(last_padded.detach().float(), self.rot_fake_s)
+                    if not self.use_plans:
+                        return fakes, fake_s, None, None
+                    return fakes, fake_s, Dt.index_plan(fakes, opt.R), Ds.index_plan(fake_s)
+                (k["fakes"], k["fake_s"], k["plan_fake_t"], k["plan_fake_s"]), k["join_fake"] = \
+                    run_index_plan(fake_side, self.side)
+            join_fs()
+            fake = Ds(fake_s_in, plan=plan_fs)
+            spatial_loss = (0.5 * (fake.float() - lab[2]) ** 2).mean()
+            join_ft()
+            fake = Dt(fake_t_in, opt.R, plan=plan_ft)
             tempo_loss = (0.5 * (fake.float() - lab[3]) ** 2).mean()
         sr_loss = tempo_loss + spatial_loss + opt.w * position_loss
         self.og.zero_grad(set_to_none=True)
         sr_loss.backward()
-        k.update(pred_lst=[p.detach() for p in pred_lst], last_padded=last_padded.detach(), tempo_loss=tempo_loss.detach(),
-                 spatial_loss=spatial_loss.detach(), cd=cd.detach(), ml=ml.detach())
+        k.update(tempo_loss=tempo_loss.detach(), spatial_loss=spatial_loss.detach(), cd=cd.detach(), ml=ml.detach())
         self.viol.copy_(viol.float().reshape(1))
+        # every side-stream branch rejoins before this segment ends (required inside a capture)
+        torch.cuda.current_stream(self.dev).wait_stream(self.side)
 
     def _seg_tempo(self, update_D):
         self.og.step()
@@ -110,11 +166,9 @@ class GraphedFluidStep:
         if not update_D:
             k["tempo_dis_loss"] = torch.zeros((), device=self.dev)
             return
-        fakes = [torch.matmul(p.float(), self.rot_fake_t[f]) for f, p in enumerate(k["pred_lst"])]
-        trues = [torch.matmul(h, self.rot_true_t[f]) for f, h in enumerate(self.high)]
         with _autocast(self.amp, self.dev):
-            fake = self.Dt(fakes, self.opt.R)
-            true = self.Dt(trues, self.opt.R)
+            fake = self.Dt(k["fakes"], self.opt.R, plan=k["plan_fake_t"])
+            true = self.Dt(k["trues"], self.opt.R, plan=k["plan_true_t"])
         loss = (0.5 * ((true.float() - lab[0]) ** 2 + (fake.float() - lab[1]) ** 2)).mean()
         self.ot.zero_grad(set_to_none=True)
         loss.backward()
@@ -126,11 +180,9 @@ class GraphedFluidStep:
             k["spatial_dis_loss"] = torch.zeros((), device=self.dev)
             return
         self.ot.step()
-        fake_cloud = torch.bmm(k["last_padded"].float(), self.rot_fake_s)
-        true_cloud = torch.bmm(self.high[1], self.rot_true_s)
         with _autocast(self.amp, self.dev):
-            fake = self.Ds(fake_cloud)
-            true = self.Ds(true_cloud)
+            fake = self.Ds(k["fake_s"], plan=k["plan_fake_s"])
+            true = self.Ds(k["true_s"], plan=k["plan_true_s"])
         loss = (0.5 * ((true.float() - lab[0]) ** 2 + (fake.float() - lab[1]) ** 2)).mean()
         self.os.zero_grad(set_to_none=True)
         loss.backward()
@@ -145,7 +197,8 @@ class GraphedFluidStep:
                                        k["spatial_loss"].reshape(()), k["spatial_dis_loss"].reshape(())]).float())
 
     def _segments(self, update_D):
-        return [("G", self._seg_generator, self.G), ("Dt", lambda: self._seg_tempo(update_D), self.Dt if update_D else None),
+        return [("G", lambda: self._seg_generator(update_D), self.G),
+                ("Dt", lambda: self._seg_tempo(update_D), self.Dt if update_D else None),
                 ("Ds", lambda: self._seg_spatial(update_D), self.Ds if update_D else None),
                 ("end", lambda: self._seg_finish(update_D), None)]
 
@@ -169,7 +222,6 @@ class GraphedFluidStep:
         known = {t.data_ptr() for t in before}
         rng = torch.cuda.get_rng_state(self.dev)
         self._load(low, high)
-        self.lab.copy_(torch.tensor([1.0, 0.1, 1.0, 1.0]))
         torch.cuda.synchronize(self.dev)
         side = torch.cuda.Stream(self.dev)
         side.wait_stream(torch.cuda.current_stream(self.dev))
@@ -229,14 +281,12 @@ class GraphedFluidStep:
                 rts = [get_rotation_matrix() for _ in range(self.B)]
                 rfs = [get_rotation_matrix() for _ in range(self.B)]
         self._load(lowres_pos_lst, highres_pos_lst)
-        self.lab.copy_(torch.tensor([valid, invalid, lab_s, lab_t], dtype=torch.float32), non_blocking=True)
-        self.perm_c.copy_(perms[0], non_blocking=True)
-        for d, s in zip(self.perm_f, perms[1:]):
-            d.copy_(s, non_blocking=True)
-        self.rot_fake_t.copy_(torch.stack(rft), non_blocking=True)
-        self.rot_true_t.copy_(torch.stack(rtt), non_blocking=True)
-        self.rot_fake_s.copy_(torch.stack(rfs), non_blocking=True)
-        self.rot_true_s.copy_(torch.stack(rts), non_blocking=True)
+        # (the previous step ended with a host sync, so the staging buffers are free to rewrite)
+        self._host_f[:4] = torch.tensor([valid, invalid, lab_s, lab_t], dtype=torch.float32)
+        self._host_f[4:] = torch.stack(rft + rtt + rfs + rts).reshape(-1)
+        self._host_i.copy_(torch.cat(perms))
+        self._dev_f.copy_(self._host_f, non_blocking=True)
+        self._dev_i.copy_(self._host_i, non_blocking=True)
         torch._foreach_copy_(self._snap, self._state)                 # pre-step snapshot (18 MB)
         for g, reduce_module in self._graphs[update_D]:
             g.replay()

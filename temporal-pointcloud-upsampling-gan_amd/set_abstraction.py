@@ -261,7 +261,19 @@ class _PointnetSAModuleBase(nn.Module):
             centres = replace_dummy_centres(xyz, centres)
         return centres
 
-    def _first_layer(self, grouper, mlp, xyz, new_xyz, feat_rows):
+    def index_level(self, xyz):
+        """All index-only work of this level for detached clouds xyz (B,N,3):
+        -> (centres (B,S) int32, new_xyz (B,S,3) detached, idx (B,S,ns) int32).
+        It depends on coordinates only, so a caller may run it ahead of time / on another stream
+        (see `index_plan` of the discriminators) and hand the result to `forward_rows`."""
+        xyz = xyz.detach().float().contiguous()
+        centres = self.sample_centres(xyz)
+        new_xyz = ops.gather_operation(xyz.transpose(1, 2).contiguous(), centres).transpose(1, 2).contiguous()
+        g = self.groupers[0]
+        idx = ops.ball_query(g.radius, g.nsample, xyz, new_xyz)
+        return centres, new_xyz, idx
+
+    def _first_layer(self, grouper, mlp, xyz, new_xyz, feat_rows, idx=None):
         """Rows of the first conv's output for every grouped position: (B,S,ns,C1)."""
         conv = mlp[0]
         with no_autocast(xyz):
@@ -271,18 +283,24 @@ class _PointnetSAModuleBase(nn.Module):
                 src = feat_rows.float()
             if isinstance(grouper, GroupAll):
                 return F.linear(src, W, conv.bias).unsqueeze(1)    # one group holding all N points
-            U = F.linear(src, W, conv.bias)                         # (B,N,C1)
-            idx = ops.ball_query(grouper.radius, grouper.nsample, xyz, new_xyz)
+            U = rows_matmul(src, W, conv.bias)                      # (B,N,C1)
+            if idx is None:
+                idx = ops.ball_query(grouper.radius, grouper.nsample, xyz, new_xyz)
             if grouper.use_xyz:
-                Q = F.linear(new_xyz, W[:, :3])                     # centre term of (xyz_j - c_i)
+                Q = rows_matmul(new_xyz, W[:, :3])                  # centre term of (xyz_j - c_i)
                 return ops.row_combine(U, Q, idx, ops.ROW_SUB, out_dtype=amp_dtype(xyz))
             return ops.row_combine(U, None, idx, ops.ROW_GATHER, out_dtype=amp_dtype(xyz))
 
-    def forward_rows(self, xyz, feat_rows):
-        """xyz (B,N,3), feat_rows (B,N,C)|None -> new_xyz (B,npoint,3)|None, (B,npoint,C') rows."""
+    def forward_rows(self, xyz, feat_rows, plan=None):
+        """xyz (B,N,3), feat_rows (B,N,C)|None -> new_xyz (B,npoint,3)|None, (B,npoint,C') rows.
+        plan = (centres, idx) from `index_level` (single-scale levels only)."""
         xyz = xyz.float().contiguous()
+        pidx = None
         if self.npoint is not None:
-            centres = self.sample_centres(xyz)
+            if plan is not None:
+                centres, pidx = plan
+            else:
+                centres = self.sample_centres(xyz)
             new_xyz = ops.gather_operation(xyz.transpose(1, 2).contiguous(), centres)
             new_xyz = new_xyz.transpose(1, 2).contiguous()
         else:
@@ -290,7 +308,7 @@ class _PointnetSAModuleBase(nn.Module):
         outs = []
         for grouper, mlp in zip(self.groupers, self.mlps):
             if rows_first():
-                y = self._first_layer(grouper, mlp, xyz, new_xyz, feat_rows)
+                y = self._first_layer(grouper, mlp, xyz, new_xyz, feat_rows, pidx)
                 outs.append(mlp_tail_rows(list(mlp)[1:], y, reduce_max=True))   # (B,S,C')
             else:                                                  # discriminator.py:139-150
                 planes = None if feat_rows is None else feat_rows.float().transpose(1, 2).contiguous()
@@ -298,7 +316,7 @@ class _PointnetSAModuleBase(nn.Module):
                 outs.append(F.max_pool2d(g, kernel_size=[1, g.size(3)]).squeeze(-1).transpose(1, 2))
         return new_xyz, torch.cat(outs, dim=-1)
 
-    def forward_rows_frames(self, xyz_lst, feat_rows_lst):
+    def forward_rows_frames(self, xyz_lst, feat_rows_lst, plan=None):
         """T frames of one clip through this level: lists of (B,N,3) / (B,N,C) -> lists.
 
         Exactly T separate `forward_rows` calls (per-frame spectral-norm power iterations,
@@ -309,14 +327,15 @@ class _PointnetSAModuleBase(nn.Module):
         T = len(xyz_lst)
         single = len(self.groupers) == 1 and isinstance(self.groupers[0], QueryAndGroup)
         if T == 1 or not rows_first() or self.npoint is None or not single or not self.groupers[0].use_xyz:
+            assert plan is None, "index plans need the stacked-frames path"
             outs = [self.forward_rows(x, f) for x, f in zip(xyz_lst, feat_rows_lst)]
             return [o[0] for o in outs], [o[1] for o in outs]
         B = xyz_lst[0].shape[0]
         grouper, mlp = self.groupers[0], self.mlps[0]
         xyz = torch.cat([x.float() for x in xyz_lst], 0).contiguous()
-        centres = self.sample_centres(xyz)
+        centres = plan[0] if plan is not None else self.sample_centres(xyz)
         new_xyz = ops.gather_operation(xyz.transpose(1, 2).contiguous(), centres).transpose(1, 2).contiguous()
-        idx = ops.ball_query(grouper.radius, grouper.nsample, xyz, new_xyz)
+        idx = plan[1] if plan is not None else ops.ball_query(grouper.radius, grouper.nsample, xyz, new_xyz)
         conv = mlp[0]
         Us, Qs = [], []
         with no_autocast(xyz):
@@ -325,8 +344,8 @@ class _PointnetSAModuleBase(nn.Module):
                 sl = slice(t * B, (t + 1) * B)
                 f = feat_rows_lst[t]
                 src = xyz[sl] if f is None else torch.cat([xyz[sl], f.float()], dim=-1)
-                Us.append(F.linear(src, W, conv.bias))
-                Qs.append(F.linear(new_xyz[sl], W[:, :3]))
+                Us.append(rows_matmul(src, W, conv.bias))
+                Qs.append(rows_matmul(new_xyz[sl], W[:, :3]))
         y = ops.row_combine(torch.cat(Us, 0), torch.cat(Qs, 0), idx, ops.ROW_SUB, out_dtype=amp_dtype(xyz))
         tail = list(mlp)[1:]
         feats = [mlp_tail_rows(tail, y[t * B:(t + 1) * B], reduce_max=True) for t in range(T)]
@@ -383,14 +402,15 @@ class FlowEmbedding(nn.Module):
             self.mlp_bns.append(nn.BatchNorm2d(out_channel))
             last = out_channel
 
-    def forward_rows(self, p1, p2, f1, f2, radius):
-        """p (B,N,3), f (B,N,C) rows -> (B,N,mlp[-1]) rows.
+    def forward_rows(self, p1, p2, f1, f2, radius, idx=None):
+        """p (B,N,3), f (B,N,C) rows -> (B,N,mlp[-1]) rows; idx = precomputed neighbour list.
 
         First conv on cat([pos2_j - pos1_i, feat2_j, feat1_i]) (discriminator.py:270-280) split
         by input columns: U = W[:, :3+C] [pos2|feat2] is gathered, Q = W[:, :3] pos1 - W[:, 3+C:] feat1
         is the per-centre term."""
         C = f1.shape[-1]
-        idx = ball_query_wrapper(radius, self.NSAMPLE, p1, p2).to(torch.int32).contiguous()
+        if idx is None:
+            idx = ball_query_wrapper(radius, self.NSAMPLE, p1, p2).to(torch.int32).contiguous()
         if not rows_first():                         # discriminator.py:270-283
             B, N, _ = p1.shape
             pos1, pos2 = p1.transpose(1, 2).contiguous(), p2.transpose(1, 2).contiguous()
@@ -403,8 +423,8 @@ class FlowEmbedding(nn.Module):
             return torch.max(x, -1)[0].transpose(1, 2)
         with no_autocast(p1):
             W = conv_weight2d(self.mlp_convs[0]).float()
-            U = F.linear(torch.cat([p2.float(), f2.float()], dim=-1), W[:, :3 + C])
-            Q = F.linear(p1.float(), W[:, :3]) - F.linear(f1.float(), W[:, 3 + C:])
+            U = rows_matmul(torch.cat([p2.float(), f2.float()], dim=-1), W[:, :3 + C])
+            Q = rows_matmul(p1.float(), W[:, :3]) - rows_matmul(f1.float(), W[:, 3 + C:])
         x = ops.row_combine(U, Q, idx, ops.ROW_SUB, out_dtype=amp_dtype(p1))     # (B,N,32,C1)
         B, N, K, _ = x.shape
         x = x.view(B * N * K, -1)
@@ -446,13 +466,22 @@ class FlowModule(nn.Module):
                 spec = (hidden_feat, [hidden_feat, hidden_feat // 2, hidden_feat])
             self.flow_emb_layers.append(FlowEmbedding(spec[0], spec[1], sn=sn))
 
-    def forward_rows(self, feat_rows_lst, pos_rows_lst, cutoff):
+    def pair_indices(self, pos_rows_lst, cutoff):
+        """Neighbour lists of the frame pairs (l, l+1): positions only, shared by every depth."""
+        return [ball_query_wrapper(cutoff, FlowEmbedding.NSAMPLE, pos_rows_lst[l].detach(),
+                                   pos_rows_lst[l + 1].detach()).to(torch.int32).contiguous()
+                for l in range(len(pos_rows_lst) - 1)]
+
+    def forward_rows(self, feat_rows_lst, pos_rows_lst, cutoff, pair_idx=None):
         """Lists of (B,N,C) / (B,N,3) rows -> (B,N,out) rows."""
         assert len(feat_rows_lst) == self.depth + 1
         feats = list(feat_rows_lst)
+        if pair_idx is None and rows_first():
+            pair_idx = self.pair_indices(pos_rows_lst, cutoff)     # depth d re-uses pairs 0..T-2-d
         for depth in range(self.depth):
             layer = self.flow_emb_layers[depth]
-            feats = [layer.forward_rows(pos_rows_lst[l], pos_rows_lst[l + 1], feats[l], feats[l + 1], cutoff)
+            feats = [layer.forward_rows(pos_rows_lst[l], pos_rows_lst[l + 1], feats[l], feats[l + 1], cutoff,
+                                        None if pair_idx is None else pair_idx[l])
                      for l in range(len(feats) - 1)]
         assert len(feats) == 1
         return feats[0]
@@ -487,15 +516,60 @@ def _head_fp32(fc_layers, x):
         return x
 
 
+def run_index_plan(make_plan, stream):
+    """Run `make_plan()` (an `index_plan` call, possibly preceded by cheap tensor prep) on
+    `stream`, forked from the current stream; returns (result, join) where `join()` makes the
+    current stream wait for exactly this piece of work.  The FPS chain is m-1 dependent rounds
+    on B workgroups: on a 256-CU part it costs latency, not throughput, so it is issued early and
+    overlapped with whatever the main stream is doing.  Works eagerly and inside hipGraph
+    capture (fork / join become graph dependencies)."""
+    main = torch.cuda.current_stream(stream.device)
+    stream.wait_stream(main)
+    with torch.cuda.stream(stream):
+        result = make_plan()
+        done = torch.cuda.Event()
+        done.record(stream)
+    for t in _plan_tensors(result):
+        t.record_stream(main)
+
+    def join():
+        torch.cuda.current_stream(stream.device).wait_event(done)
+    return result, join
+
+
+def _plan_tensors(obj):
+    """Every tensor inside a (nested) plan / tuple / list / dict."""
+    if torch.is_tensor(obj):
+        return [obj]
+    if isinstance(obj, dict):
+        obj = list(obj.values())
+    if isinstance(obj, (list, tuple)):
+        return [t for o in obj for t in _plan_tensors(o)]
+    return []
+
+
 class _TempoDis(nn.Module):
     """Per-frame SA x2 -> FlowModule over the T frames -> GroupAll SA -> FC head."""
 
     flow_radius_scale = 1.0
 
-    def _levels(self, pos_lst, feat_lst):
+    def index_plan(self, pos_lst, cutoff):
+        """Every index of one forward over the frames `pos_lst` -- FPS centres and ball-query
+        lists of both levels (frames stacked) and the flow-embedding neighbour lists.  Depends on
+        coordinates only; see `run_index_plan` for running it on a side stream."""
+        T, B = len(pos_lst), pos_lst[0].shape[0]
+        xyz = torch.cat([p.detach().float() for p in pos_lst], 0)
+        c0, x1, i0 = self.coarse_graining_module[0].index_level(xyz)
+        c1, x2, i1 = self.coarse_graining_module[1].index_level(x1)
+        pairs = self.flow_module.pair_indices([x2[t * B:(t + 1) * B] for t in range(T)],
+                                              self.flow_radius_scale * cutoff)
+        return {"sa": [(c0, i0), (c1, i1)], "flow": pairs}
+
+    def _levels(self, pos_lst, feat_lst, plan=None):
         feats0 = list(feat_lst) if feat_lst is not None else list(pos_lst)
-        poss, feats = self.coarse_graining_module[0].forward_rows_frames(list(pos_lst), feats0)
-        poss2, feats2 = self.coarse_graining_module[1].forward_rows_frames(poss, feats)
+        sa = plan["sa"] if plan is not None else (None, None)
+        poss, feats = self.coarse_graining_module[0].forward_rows_frames(list(pos_lst), feats0, sa[0])
+        poss2, feats2 = self.coarse_graining_module[1].forward_rows_frames(poss, feats, sa[1])
         return feats2, poss2
 
     def _sn_calls(self, T):
@@ -509,12 +583,13 @@ class _TempoDis(nn.Module):
         calls += [(m, 1) for m in self.fc_layers.modules() if isinstance(m, nn.Linear)]
         return calls
 
-    def _forward(self, pos_lst, cutoff, feat_lst, width):
+    def _forward(self, pos_lst, cutoff, feat_lst, width, plan=None):
         if feat_lst is not None:
             assert len(feat_lst) == len(pos_lst)
         with sn_prefetch(self._sn_calls(len(pos_lst)), self.training):
-            feats, poss = self._levels(pos_lst, feat_lst)           # rows all the way
-            f = self.flow_module.forward_rows(feats, poss, self.flow_radius_scale * cutoff)
+            feats, poss = self._levels(pos_lst, feat_lst, plan)     # rows all the way
+            f = self.flow_module.forward_rows(feats, poss, self.flow_radius_scale * cutoff,
+                                              None if plan is None else plan["flow"])
             _, f = self.SA_pooling.forward_rows(poss[0], f)
             return _head_fp32(self.fc_layers, f.reshape(-1, width))
 
@@ -529,8 +604,8 @@ class ActionTempoDis(_TempoDis):
         self.SA_pooling = SSGSetConv(mlp=[256, 256, 512], use_xyz=True, sn=sn)
         self.fc_layers = _head([512, 256, 64, 1], [0.3, 0.1])
 
-    def forward(self, pos_lst, cutoff):
-        return self._forward(pos_lst, cutoff, None, 512)
+    def forward(self, pos_lst, cutoff, plan=None):
+        return self._forward(pos_lst, cutoff, None, 512, plan)
 
 
 class FluidTempoDis(_TempoDis):
@@ -547,8 +622,8 @@ class FluidTempoDis(_TempoDis):
         self.SA_pooling = SSGSetConv(mlp=[256, 256, 256], use_xyz=True, sn=sn, act_fn=nn.LeakyReLU())
         self.fc_layers = _head([256, 256, 64, 1], [0.2, 0.0])
 
-    def forward(self, pos_lst, cutoff, feat_lst=None):
-        return self._forward(pos_lst, cutoff, feat_lst, 256)
+    def forward(self, pos_lst, cutoff, feat_lst=None, plan=None):
+        return self._forward(pos_lst, cutoff, feat_lst, 256, plan)
 
 
 class _SpatialDis(nn.Module):
@@ -559,11 +634,20 @@ class _SpatialDis(nn.Module):
         calls += [(m, 1) for m in self.fc_layers.modules() if isinstance(m, nn.Linear)]
         return calls
 
-    def _forward(self, pos, width):
+    def index_plan(self, pos):
+        """FPS centres + ball-query lists of every level for the clouds `pos` (coordinates only)."""
+        xyz, levels = pos.detach().float(), []
+        for sa in self.coarse_graining_module:
+            c, xyz, i = sa.index_level(xyz)
+            levels.append((c, i))
+        return {"sa": levels}
+
+    def _forward(self, pos, width, plan=None):
         with sn_prefetch(self._sn_calls(), self.training):
             feature = None
-            for sa in self.coarse_graining_module:
-                pos, feature = sa.forward_rows(pos, pos if feature is None else feature)
+            for l, sa in enumerate(self.coarse_graining_module):
+                pos, feature = sa.forward_rows(pos, pos if feature is None else feature,
+                                               None if plan is None else plan["sa"][l])
             _, feature = self.SA_pooling.forward_rows(pos, feature)
             return _head_fp32(self.fc_layers, feature.reshape(-1, width))
 
@@ -578,8 +662,8 @@ class ActionSpatialDis(_SpatialDis):
         self.SA_pooling = SSGSetConv(mlp=[256, 256, 512], use_xyz=True, sn=sn)
         self.fc_layers = _head([512, 256, 64, 1], [0.3, 0.1])
 
-    def forward(self, pos):
-        return self._forward(pos, 512)
+    def forward(self, pos, plan=None):
+        return self._forward(pos, 512, plan)
 
 
 class FluidSpatialDis(_SpatialDis):
@@ -596,5 +680,5 @@ class FluidSpatialDis(_SpatialDis):
         self.SA_pooling = SSGSetConv(mlp=[256, 256, 256], use_xyz=True, sn=sn)
         self.fc_layers = _head([256, 256, 64, 1], [0.2, 0.0])
 
-    def forward(self, pos):
-        return self._forward(pos, 256)
+    def forward(self, pos, plan=None):
+        return self._forward(pos, 256, plan)
