@@ -55,7 +55,7 @@ class GraphedFluidStep:
         self.G, self.Ds, self.Dt = sr_net, spatial_dis, tempo_dis
         self.og, self.ot, self.os = optims
         for o in optims:
-            if not all(g.get("capturable", False) for g in o.param_groups):
+            if not all(g.get("capturable", True) for g in o.param_groups):   # Adam & co. expose the flag
                 raise ValueError("graph capture needs optimizers built with capturable=True")
         self.opt, self.fd, self.amp = opt, furthest_distance, amp_dtype
         self.sync = sync or _NoSync()
