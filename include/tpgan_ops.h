@@ -140,18 +140,23 @@ int tpg_rowcombine_bwd(const void *gout, const int32_t *idx, const int32_t *offs
  * training != 0: mean / rstd are computed from x (biased variance, eps) and written; running
  * statistics (may be NULL) are updated with `momentum` and the unbiased variance.
  * training == 0: mean / rstd are inputs (the caller derives them from the running statistics).
- * ws: tpg_rowbn_workspace_bytes(C) bytes of scratch.  gamma / beta may be NULL (1 / 0). */
+ * ws: tpg_rowbn_workspace_bytes(C) bytes of scratch.  gamma / beta may be NULL (1 / 0).
+ * phase: TPG_BN_PHASE_ALL, or the reduction part / the streaming part alone (two calls with the
+ * same arguments and workspace = one ALL call; lets a profiler time each kernel by itself). */
+#define TPG_BN_PHASE_ALL 0
+#define TPG_BN_PHASE_STATS 1
+#define TPG_BN_PHASE_APPLY 2
 size_t tpg_rowbn_workspace_bytes(int C);
 int tpg_rowbn_fwd(const void *x, int dtype_in, long long P, int K, int C, float eps, float momentum,
                   int training, float *running_mean, float *running_var, const float *gamma,
                   const float *beta, float slope, float *mean, float *rstd, void *y, int dtype_out,
-                  uint8_t *argmax, void *ws, void *stream);
+                  uint8_t *argmax, void *ws, int phase, void *stream);
 /* gy: (P,C) for K == 0, (P/K,C) for K > 0, of dtype_g; dx (P,C) of dtype_in; dgamma / dbeta (C) f32
  * (may be NULL). */
 int tpg_rowbn_bwd(const void *gy, int dtype_g, const void *x, int dtype_in, const uint8_t *argmax,
                   long long P, int K, int C, int training, const float *mean, const float *rstd,
                   const float *gamma, const float *beta, float slope, float *dgamma, float *dbeta,
-                  void *dx, void *ws, void *stream);
+                  void *dx, void *ws, int phase, void *stream);
 
 /* ---- fused spectral normalisation of a (R x Cn) conv / linear weight ------------------------
  * torch.nn.utils.spectral_norm's forward pre-hook (n_power_iterations = 1) on every conv and

@@ -519,7 +519,7 @@ extern "C" size_t tpg_rowbn_workspace_bytes(int C) {
 extern "C" int tpg_rowbn_fwd(const void *x, int dtype_in, long long P, int K, int C, float eps, float momentum,
                              int training, float *running_mean, float *running_var, const float *gamma,
                              const float *beta, float slope, float *mean, float *rstd, void *y, int dtype_out,
-                             uint8_t *argmax, void *ws, void *stream) {
+                             uint8_t *argmax, void *ws, int phase, void *stream) {
     if (P <= 0 || C <= 0 || K < 0 || K > 256 || (K > 0 && P % K)) return TPG_ERR_ARG;
     if (!x || !mean || !rstd || !y || !ws || (K > 0 && !argmax)) return TPG_ERR_ARG;
     if (!bn_dtype_ok(dtype_in) || !bn_dtype_ok(dtype_out) || !bn_shape_ok(dtype_in, dtype_out, C))
@@ -527,7 +527,7 @@ extern "C" int tpg_rowbn_fwd(const void *x, int dtype_in, long long P, int K, in
     if ((reinterpret_cast<uintptr_t>(x) | reinterpret_cast<uintptr_t>(y)) & 15) return TPG_ERR_UNSUPPORTED;
     hipStream_t st = tpg_stream(stream);
     float *part = static_cast<float *>(ws);
-    if (training) {
+    if (training && phase != TPG_BN_PHASE_APPLY) {
         // statistics use the INPUT type's vector width
         const int ne = dtype_in == TPG_DTYPE_BF16 ? 8 : 4;
         const int rpi = BN_THREADS / (C / ne);
@@ -544,6 +544,10 @@ extern "C" int tpg_rowbn_fwd(const void *x, int dtype_in, long long P, int K, in
                                P, C, eps, momentum, running_mean, running_var, mean, rstd);
         }
     }  // eval mode: the caller has filled mean / rstd from the running statistics
+    if (phase == TPG_BN_PHASE_STATS) {
+        TPG_RETURN_IF_LAUNCH_FAILED();
+        return TPG_OK;
+    }
     const int ne = (dtype_in == TPG_DTYPE_BF16 || dtype_out == TPG_DTYPE_BF16) ? 8 : 4;
     const int rpi_a = BN_THREADS / (C / ne);
     const long long rows_out = K > 0 ? P / K : P;
@@ -570,7 +574,7 @@ extern "C" int tpg_rowbn_fwd(const void *x, int dtype_in, long long P, int K, in
 extern "C" int tpg_rowbn_bwd(const void *gy, int dtype_g, const void *x, int dtype_in, const uint8_t *argmax,
                              long long P, int K, int C, int training, const float *mean, const float *rstd,
                              const float *gamma, const float *beta, float slope, float *dgamma, float *dbeta,
-                             void *dx, void *ws, void *stream) {
+                             void *dx, void *ws, int phase, void *stream) {
     if (P <= 0 || C <= 0 || K < 0 || K > 256 || (K > 0 && P % K)) return TPG_ERR_ARG;
     if (!gy || !x || !mean || !rstd || !dx || !ws || (K > 0 && !argmax)) return TPG_ERR_ARG;
     if (!bn_dtype_ok(dtype_in) || !bn_dtype_ok(dtype_g) || !bn_shape_ok(dtype_in, dtype_g, C))
@@ -587,8 +591,9 @@ extern "C" int tpg_rowbn_bwd(const void *gy, int dtype_g, const void *x, int dty
     const int GA = K > 0 ? row_blocks(rows_g, rpi, 1, 8192) : row_blocks(P, rpi, 4, 4096);
     // no batch statistics and no affine gradients wanted (pure activation [+max]): dx = a * g,
     // nothing to reduce
-    const bool need_reduce = training || dgamma || dbeta;
-    if (!need_reduce && hipMemsetAsync(c12, 0, sizeof(float) * 2 * (size_t)C, st) != hipSuccess)
+    const bool need_reduce = (training || dgamma || dbeta) && phase != TPG_BN_PHASE_APPLY;
+    const bool do_apply = phase != TPG_BN_PHASE_STATS;
+    if (!(training || dgamma || dbeta) && phase != TPG_BN_PHASE_APPLY && hipMemsetAsync(c12, 0, sizeof(float) * 2 * (size_t)C, st) != hipSuccess)
         return TPG_ERR_LAUNCH;
 #define TPG_BN_BWD(TI, TG)                                                                                  \
     do {                                                                                                    \
@@ -604,8 +609,9 @@ extern "C" int tpg_rowbn_bwd(const void *gy, int dtype_g, const void *x, int dty
         if (need_reduce)                                                                                    \
             hipLaunchKernelGGL(rowbn_bwd_finalize_kernel, dim3((C + FIN_CH - 1) / FIN_CH), dim3(BN_THREADS), 0, st, part, G, P, C, \
                                training, dgamma, dbeta, c12);                                               \
-        hipLaunchKernelGGL((rowbn_bwd_apply_kernel<TI, TG>), dim3(GA), dim3(BN_THREADS), 0, st, gg, xx, argmax, \
-                           P, K, C, mean, rstd, gamma, beta, slope, c12, static_cast<TI *>(dx));          \
+        if (do_apply)                                                                                       \
+            hipLaunchKernelGGL((rowbn_bwd_apply_kernel<TI, TG>), dim3(GA), dim3(BN_THREADS), 0, st, gg, xx, argmax, \
+                               P, K, C, mean, rstd, gamma, beta, slope, c12, static_cast<TI *>(dx));      \
     } while (0)
     if (dtype_in == TPG_DTYPE_F32 && dtype_g == TPG_DTYPE_F32) TPG_BN_BWD(float, float);
     else if (dtype_in == TPG_DTYPE_F32) TPG_BN_BWD(float, __hip_bfloat16);

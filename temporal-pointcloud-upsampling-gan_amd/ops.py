@@ -277,11 +277,17 @@ class HipBackend:
         y = torch.empty((rows, Cc), dtype=out_dtype, device=x.device)
         arg = torch.empty((rows, Cc), dtype=torch.uint8, device=x.device) if K else None
         ws = self._bn_ws(x, Cc)
-        nbytes = x.element_size() * P * Cc * (2 if training else 1) + y.element_size() * rows * Cc
-        self._call("tpg_rowbn_fwd", "rowbn_fwd", nbytes, x,
-                   _ptr(x), _DTYPE_CODE[x.dtype], P, K, Cc, float(eps), float(momentum), int(training),
-                   _ptr(running_mean), _ptr(running_var), _ptr(gamma), _ptr(beta), float(slope), _ptr(mean),
-                   _ptr(rstd), _ptr(y), _DTYPE_CODE[out_dtype], _ptr(arg), _ptr(ws))
+        args = (_ptr(x), _DTYPE_CODE[x.dtype], P, K, Cc, float(eps), float(momentum), int(training),
+                _ptr(running_mean), _ptr(running_var), _ptr(gamma), _ptr(beta), float(slope), _ptr(mean),
+                _ptr(rstd), _ptr(y), _DTYPE_CODE[out_dtype], _ptr(arg), _ptr(ws))
+        b_stats = x.element_size() * P * Cc
+        b_apply = x.element_size() * P * Cc + y.element_size() * rows * Cc + (rows * Cc if K else 0)
+        if _timer is None:
+            self._call("tpg_rowbn_fwd", "rowbn_fwd", b_stats + b_apply, x, *args, 0)
+        else:       # time the reduction and the streaming kernel separately (one kernel each + finalize)
+            if training:
+                self._call("tpg_rowbn_fwd", "rowbn_fwd_stats", b_stats, x, *args, 1)
+            self._call("tpg_rowbn_fwd", "rowbn_fwd_apply_max" if K else "rowbn_fwd_apply", b_apply, x, *args, 2)
         return y, arg
 
     def rowbn_bwd(self, gy, x, arg, K, training, mean, rstd, gamma, beta, slope, need_affine):
@@ -290,11 +296,17 @@ class HipBackend:
         dgamma = torch.empty(Cc, dtype=torch.float32, device=x.device) if need_affine else None
         dbeta = torch.empty(Cc, dtype=torch.float32, device=x.device) if need_affine else None
         ws = self._bn_ws(x, Cc)
-        nbytes = 2 * gy.element_size() * gy.numel() + x.element_size() * P * Cc * 3
-        self._call("tpg_rowbn_bwd", "rowbn_bwd", nbytes, x,
-                   _ptr(gy), _DTYPE_CODE[gy.dtype], _ptr(x), _DTYPE_CODE[x.dtype], _ptr(arg), P, K, Cc,
-                   int(training), _ptr(mean), _ptr(rstd), _ptr(gamma), _ptr(beta), float(slope), _ptr(dgamma),
-                   _ptr(dbeta), _ptr(dx), _ptr(ws))
+        args = (_ptr(gy), _DTYPE_CODE[gy.dtype], _ptr(x), _DTYPE_CODE[x.dtype], _ptr(arg), P, K, Cc,
+                int(training), _ptr(mean), _ptr(rstd), _ptr(gamma), _ptr(beta), float(slope), _ptr(dgamma),
+                _ptr(dbeta), _ptr(dx), _ptr(ws))
+        b_gy = gy.element_size() * gy.numel() + (gy.numel() if K else 0)
+        b_reduce = b_gy + x.element_size() * (gy.numel() if K else P * Cc)
+        b_apply = b_gy + 2 * x.element_size() * P * Cc
+        if _timer is None:
+            self._call("tpg_rowbn_bwd", "rowbn_bwd", b_reduce + b_apply, x, *args, 0)
+        else:
+            self._call("tpg_rowbn_bwd", "rowbn_bwd_reduce", b_reduce, x, *args, 1)
+            self._call("tpg_rowbn_bwd", "rowbn_bwd_apply", b_apply, x, *args, 2)
         return dx, dgamma, dbeta
 
 
