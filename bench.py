@@ -120,15 +120,35 @@ def roofline_leg(models, clips, steps, sync, amp_dtype):
         ops.set_timer(None)
         GRAPHED = saved
     summ = timer.summary()
-    name = max(summ, key=lambda k: summ[k]["total_ms"])
+    # Streaming kernels are priced against the HBM roofline; furthest-point sampling and the
+    # neighbour searches are chains of dependent rounds on cache-resident clouds (latency /
+    # issue bound by construction) and are listed with their own figure instead.
+    streaming = [k for k in summ if k.startswith(("rowbn_", "rowcombine_", "group_"))]
+    name = max(streaming or list(summ), key=lambda k: summ[k]["total_ms"])
     dom = summ[name]
     roof = {"bound": "hbm", "kernel": name, "achieved": round(dom["gbps"], 2), "peak": HBM_PEAK_GBPS,
-            "unit": "GB/s", "frac": round(dom["gbps"] / HBM_PEAK_GBPS, 6), "traffic": None,
+            "unit": "GB/s", "frac": round(dom["gbps"] / HBM_PEAK_GBPS, 6), "traffic": pmc_traffic(name),
             "avg_launch_us": round(dom["avg_us"], 2), "launches_per_step": dom["launches"] / steps,
-            "algorithmic_bytes_per_launch": int(dom["bytes_per_launch"])}
+            "algorithmic_bytes_per_launch": int(dom["bytes_per_launch"]),
+            "selection": "largest total time among the HBM-streaming kernels; timed per launch with HIP "
+                         "events in an eager (non-graph) pass over the same steps"}
     table = {k: {"launches_per_step": v["launches"] / steps, "ms_per_step": round(v["total_ms"] / steps, 4),
                  "avg_us": round(v["avg_us"], 2), "GBps": round(v["gbps"], 1)} for k, v in summ.items()}
+    if "fps" in summ:
+        table["fps"]["note"] = "npoint-1 dependent rounds per launch; hidden on a side stream in graph mode"
     return roof, table
+
+
+def pmc_traffic(kernel):
+    """HBM bytes per launch of `kernel` from the committed rocprofv3 PMC passes (profiles/), with the
+    gfx950 FETCH_SIZE x2 correction for wide coalesced reads; None when no PMC file is present."""
+    path = os.path.join(ROOT, "profiles", "r01_pmc_traffic.json")
+    try:
+        with open(path) as fh:
+            rec = json.load(fh).get(kernel)
+        return None if rec is None else rec["hbm_bytes_per_launch"]
+    except (OSError, ValueError, KeyError):
+        return None
 
 
 def main():
