@@ -43,6 +43,7 @@ def test_graph_replay_equals_eager(segmented):
     Bm = copy.deepcopy(A)
     oa, ob = _optims(*A), _optims(*Bm)
     clips = [fluid_clip(2, 1024, 8, 3, seed=s, device=dev) for s in (1, 2)]
+    init = [[p.detach().clone() for p in m.parameters()] for m in A]
     stepper = GraphedFluidStep(Bm[0], Bm[1], Bm[2], ob, OPT, clips[0][0], clips[0][1], 1.0, None, None,
                                segmented=segmented)
     # capture must leave the model untouched
@@ -59,11 +60,16 @@ def test_graph_replay_equals_eager(segmented):
     for k in le:
         assert abs(le[k] - lg[k]) <= 2e-3 * max(1.0, abs(le[k])), (k, le[k], lg[k])
     assert le["tempo_D_loss"] > 0 and le["masking_loss"] < 0.1          # full G+D update, gate open
-    for ma, mb in zip(A, Bm):
-        for (n, pa), (_, pb) in zip(ma.named_parameters(), mb.named_parameters()):
-            rel = float((pa - pb).norm() / pa.norm().clamp_min(1e-6))
-            # max-pool / arg-max routing flips on near-ties move a few gradient entries by O(1)
-            assert rel <= 6e-2, (n, rel)
+    # SGD deltas = -lr * gradients.  Compared per NETWORK in L2: single tensors can be pure
+    # round-off (e.g. everything upstream of the head's BatchNorm1d over a batch of 2 has an
+    # analytically ~zero gradient that is noise amplified by 1/sqrt(eps)), and max-pool arg-max
+    # flips on near-ties move a few entries by O(1).
+    for ma, mb, m0 in zip(A, Bm, init):
+        da = torch.cat([(p - q).reshape(-1) for p, q in zip(ma.parameters(), m0)])
+        db = torch.cat([(p - q).reshape(-1) for p, q in zip(mb.parameters(), m0)])
+        assert float(da.norm()) > 0
+        rel = float((da - db).norm() / da.norm())
+        assert rel <= 5e-2, rel
     # later steps are not comparable number for number (an untrained generator's near-coincident
     # points make FPS / kNN decisions chaotic under 1e-7 differences); the replay must simply keep
     # working in the static regime, for G-only (odd) and G+D (even) iterations alike
