@@ -55,9 +55,16 @@ def build(device, seed=1, capturable=False):
     Ds = FluidSpatialDis().to(device)
     Dt = FluidTempoDis(3).to(device)
     lr = 3e-4
-    kw = {"capturable": True} if capturable else {}
-    opts = (torch.optim.Adam(G.parameters(), lr=lr, **kw), torch.optim.Adam(Dt.parameters(), lr=0.33 * lr, **kw),
-            torch.optim.Adam(Ds.parameters(), lr=0.33 * lr, **kw))
+    # capturable for the hipGraph path; fused = torch's single-launch multi-tensor Adam (the
+    # foreach form divides by per-parameter 0-dim step tensors one launch per parameter)
+    kw = {"capturable": True, "fused": torch.device(device).type == "cuda"} if capturable else {}
+
+    def adam(params, lr_):
+        try:
+            return torch.optim.Adam(params, lr=lr_, **kw)
+        except (RuntimeError, ValueError):
+            return torch.optim.Adam(params, lr=lr_, **{k: v for k, v in kw.items() if k != "fused"})
+    opts = (adam(list(G.parameters()), lr), adam(list(Dt.parameters()), 0.33 * lr), adam(list(Ds.parameters()), 0.33 * lr))
     return G, Ds, Dt, opts
 
 

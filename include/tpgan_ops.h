@@ -138,8 +138,10 @@ int tpg_rowcombine_bwd(const void *gout, const int32_t *idx, const int32_t *offs
  *   K == 0: y (P,C).   K > 0: y (P/K,C) = max over each group of K consecutive rows, plus the
  *   arg-max row of every (group, channel) as one byte (first maximum).
  * training != 0: mean / rstd are computed from x (biased variance, eps) and written; running
- * statistics (may be NULL) are updated with `momentum` and the unbiased variance.
- * training == 0: mean / rstd are inputs (the caller derives them from the running statistics).
+ * statistics (may be NULL) are updated with `momentum` and the unbiased variance, and
+ * *num_batches_tracked (may be NULL) is incremented, as nn.BatchNorm's forward does.
+ * training == 0: mean / rstd are inputs (the caller derives them from the running statistics);
+ * both NULL = identity statistics (mean 0, rstd 1: a pure activation [+ max]).
  * ws: tpg_rowbn_workspace_bytes(C) bytes of scratch.  gamma / beta may be NULL (1 / 0).
  * phase: TPG_BN_PHASE_ALL, or the reduction part / the streaming part alone (two calls with the
  * same arguments and workspace = one ALL call; lets a profiler time each kernel by itself). */
@@ -148,15 +150,19 @@ int tpg_rowcombine_bwd(const void *gout, const int32_t *idx, const int32_t *offs
 #define TPG_BN_PHASE_APPLY 2
 size_t tpg_rowbn_workspace_bytes(int C);
 int tpg_rowbn_fwd(const void *x, int dtype_in, long long P, int K, int C, float eps, float momentum,
-                  int training, float *running_mean, float *running_var, const float *gamma,
-                  const float *beta, float slope, float *mean, float *rstd, void *y, int dtype_out,
-                  uint8_t *argmax, void *ws, int phase, void *stream);
+                  int training, float *running_mean, float *running_var, long long *num_batches_tracked,
+                  const float *gamma, const float *beta, float slope, float *mean, float *rstd, void *y,
+                  int dtype_out, uint8_t *argmax, void *ws, int phase, void *stream);
 /* gy: (P,C) for K == 0, (P/K,C) for K > 0, of dtype_g; dx (P,C) of dtype_in; dgamma / dbeta (C) f32
- * (may be NULL). */
+ * (may be NULL).  y / dtype_y (K > 0 only, may be NULL): the forward's output; with it the
+ * per-channel sums of the max variant are taken from (gy, y) alone -- the pre-activation of the
+ * arg-max row is recovered from y -- instead of gathering one element of x per (group, channel);
+ * channels where that inversion is ill-conditioned (|beta| > 4|gamma|, or slope == 0 and
+ * y == 0 carrying no gradient anyway) use the gather. */
 int tpg_rowbn_bwd(const void *gy, int dtype_g, const void *x, int dtype_in, const uint8_t *argmax,
-                  long long P, int K, int C, int training, const float *mean, const float *rstd,
-                  const float *gamma, const float *beta, float slope, float *dgamma, float *dbeta,
-                  void *dx, void *ws, int phase, void *stream);
+                  const void *y, int dtype_y, long long P, int K, int C, int training, const float *mean,
+                  const float *rstd, const float *gamma, const float *beta, float slope, float *dgamma,
+                  float *dbeta, void *dx, void *ws, int phase, void *stream);
 
 /* ---- fused spectral normalisation of a (R x Cn) conv / linear weight ------------------------
  * torch.nn.utils.spectral_norm's forward pre-hook (n_power_iterations = 1) on every conv and

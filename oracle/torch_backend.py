@@ -86,12 +86,17 @@ class OracleBackend:
 
     # ---- fused BatchNorm + act (+max) on rows ---------------------------------------------
     def rowbn_fwd(self, x, K, eps, momentum, training, running_mean, running_var, gamma, beta, slope, mean,
-                  rstd, out_dtype):
+                  rstd, out_dtype, num_batches_tracked=None):
+        Cc = x.shape[1]
+        if not training and mean is None:            # identity statistics
+            mean, rstd = torch.zeros(Cc), torch.ones(Cc)
         y, m, r, arg = R.rowbn_fwd(_np(x.float()), K, eps, _np(gamma), _np(beta), slope, training,
                                    None if training else _np(mean), None if training else _np(rstd))
         if training:
             mean.copy_(_t(m))
             rstd.copy_(_t(r))
+            if num_batches_tracked is not None:
+                num_batches_tracked.add_(1)
             if running_mean is not None:
                 P = x.shape[0]
                 var = (1.0 / (_t(r).double() ** 2) - eps) * (P / max(P - 1, 1))
@@ -99,7 +104,9 @@ class OracleBackend:
                 running_var.mul_(1 - momentum).add_((momentum * var).float())
         return _t(y).to(out_dtype), (None if arg is None else _t(arg))
 
-    def rowbn_bwd(self, gy, x, arg, K, training, mean, rstd, gamma, beta, slope, need_affine):
+    def rowbn_bwd(self, gy, x, arg, K, training, mean, rstd, gamma, beta, slope, need_affine, y=None):
+        if mean is None:
+            mean, rstd = torch.zeros(x.shape[1]), torch.ones(x.shape[1])
         dx, dg, db = R.rowbn_bwd(_np(gy.float()), _np(x.float()), _np(arg), K, training, _np(mean), _np(rstd),
                                  _np(gamma), _np(beta), slope)
         return _t(dx).to(x.dtype), (_t(dg) if need_affine else None), (_t(db) if need_affine else None)

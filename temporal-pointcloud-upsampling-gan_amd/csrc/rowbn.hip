@@ -72,6 +72,9 @@ template <> struct BnIO<__hip_bfloat16, 8> {
 template <typename T> struct BnElems { static constexpr int NE = sizeof(T) == 2 ? 8 : 4; };
 
 __device__ __forceinline__ float lrelu_f(float z, float slope) { return z > 0.0f ? z : z * slope; }
+// NULL statistics = identity (mean 0, rstd 1)
+__device__ __forceinline__ float ld_mean(const float *mean, int c) { return mean ? mean[c] : 0.0f; }
+__device__ __forceinline__ float ld_rstd(const float *rstd, int c) { return rstd ? rstd[c] : 1.0f; }
 // pre-activation, written ONCE so that forward and backward see the same sign
 __device__ __forceinline__ float bn_z(float v, float mu, float a, float beta) { return (v - mu) * a + beta; }
 
@@ -185,9 +188,10 @@ template <typename T>
 __global__ __launch_bounds__(BN_THREADS) void rowbn_stats_finalize_kernel(
     const T *__restrict__ x, const float *__restrict__ part, int G, long long P, int C, float eps,
     float momentum, float *__restrict__ running_mean, float *__restrict__ running_var,
-    float *__restrict__ mean, float *__restrict__ rstd) {
+    long long *__restrict__ num_batches_tracked, float *__restrict__ mean, float *__restrict__ rstd) {
     int c;
     double s, ss;
+    if (num_batches_tracked && blockIdx.x == 0 && threadIdx.x == 0) *num_batches_tracked += 1;
     if (!finalize_sums(part, G, C, c, s, ss)) return;
     const double piv = BnIO<T, BnElems<T>::NE>::one(x + c);
     const double m = s / (double)P;
@@ -215,8 +219,8 @@ __global__ __launch_bounds__(BN_THREADS) void rowbn_apply_kernel(
     float a[NE], b[NE], mu[NE];
 #pragma unroll
     for (int i = 0; i < NE; ++i) {
-        mu[i] = mean[col + i];
-        a[i] = (gamma ? gamma[col + i] : 1.0f) * rstd[col + i];
+        mu[i] = ld_mean(mean, col + i);
+        a[i] = (gamma ? gamma[col + i] : 1.0f) * ld_rstd(rstd, col + i);
         b[i] = beta ? beta[col + i] : 0.0f;
     }
     const long long step = (long long)gridDim.x * rpi;
@@ -254,8 +258,8 @@ __global__ __launch_bounds__(BN_THREADS) void rowbn_apply_max_kernel(
     float a[NE], b[NE], mu[NE];
 #pragma unroll
     for (int i = 0; i < NE; ++i) {
-        mu[i] = mean[col + i];
-        a[i] = (gamma ? gamma[col + i] : 1.0f) * rstd[col + i];
+        mu[i] = ld_mean(mean, col + i);
+        a[i] = (gamma ? gamma[col + i] : 1.0f) * ld_rstd(rstd, col + i);
         b[i] = beta ? beta[col + i] : 0.0f;
     }
     for (long long grp = (long long)blockIdx.x * rpi + rsub; grp < Gp; grp += (long long)gridDim.x * rpi) {
@@ -315,7 +319,7 @@ __global__ __launch_bounds__(BN_THREADS) void rowbn_bwd_reduce_kernel(
     for (int i = 0; i < NE; ++i) {
         acc[0][i] = 0.0f; acc[1][i] = 0.0f;
         const int c = chunk * NE + i;
-        mu[i] = mean[c]; rs[i] = rstd[c];
+        mu[i] = ld_mean(mean, c); rs[i] = ld_rstd(rstd, c);
         a[i] = (gamma ? gamma[c] : 1.0f) * rs[i];
         b[i] = beta ? beta[c] : 0.0f;
     }
@@ -354,7 +358,62 @@ __global__ __launch_bounds__(BN_THREADS) void rowbn_bwd_reduce_kernel(
     block_column_reduce<2, NE>(acc, cpr, rpi, C, part);
 }
 
-// max variant: gy is (P/K, C); only the arg-max row of each group carries gradient
+// max variant: gy is (P/K, C); only the arg-max row of each group carries gradient.
+// With the forward's output y (stored like gy) the arg-max row's pre-activation is
+// z = y > 0 ? y : y / slope and xhat = (z - beta) / gamma: two small streaming reads instead of
+// one scattered 2/4-byte load of x per (group, channel).  Per-channel guard: the inversion is
+// used only where it is well conditioned.
+template <typename TI, typename TG>
+__global__ __launch_bounds__(BN_THREADS) void rowbn_bwd_reduce_max_y_kernel(
+    const TG *__restrict__ gy, const TG *__restrict__ y, const TI *__restrict__ x,
+    const uint8_t *__restrict__ arg, long long Gp, int K, int C, const float *__restrict__ mean,
+    const float *__restrict__ rstd, const float *__restrict__ gamma, const float *__restrict__ beta,
+    float slope, float *__restrict__ part) {
+    constexpr int NE = (sizeof(TI) == 2 || sizeof(TG) == 2) ? 8 : 4;
+    const int cpr = C / NE, rpi = BN_THREADS / cpr;
+    const int tid = threadIdx.x;
+    const int chunk = tid % cpr, rsub = tid / cpr;
+    float acc[2][NE], a[NE], b[NE], mu[NE], rs[NE], ig[NE];
+    bool inv[NE];
+    const float islope = slope != 0.0f ? 1.0f / slope : 0.0f;
+#pragma unroll
+    for (int i = 0; i < NE; ++i) {
+        acc[0][i] = 0.0f; acc[1][i] = 0.0f;
+        const int c = chunk * NE + i;
+        mu[i] = ld_mean(mean, c); rs[i] = ld_rstd(rstd, c);
+        const float gm = gamma ? gamma[c] : 1.0f;
+        a[i] = gm * rs[i];
+        b[i] = beta ? beta[c] : 0.0f;
+        inv[i] = fabsf(b[i]) <= 4.0f * fabsf(gm);
+        ig[i] = inv[i] ? 1.0f / gm : 0.0f;
+    }
+    if (rsub < rpi) {
+        for (long long r = (long long)blockIdx.x * rpi + rsub; r < Gp; r += (long long)gridDim.x * rpi) {
+            float g[NE], yy[NE];
+            BnIO<TG, NE>::load(gy + r * C + chunk * NE, g);
+            BnIO<TG, NE>::load(y + r * C + chunk * NE, yy);
+#pragma unroll
+            for (int i = 0; i < NE; ++i) {
+                const int c = chunk * NE + i;
+                if (inv[i]) {
+                    const bool pos = yy[i] > 0.0f;
+                    const float gg = pos ? g[i] : g[i] * slope;
+                    const float z = pos ? yy[i] : yy[i] * islope;
+                    acc[0][i] += gg;
+                    acc[1][i] += gg * ((z - b[i]) * ig[i]);
+                } else {
+                    const int k = arg[r * C + c];
+                    const float v = BnIO<TI, NE>::one(x + (r * K + k) * C + c);
+                    const float gg = bn_z(v, mu[i], a[i], b[i]) > 0.0f ? g[i] : g[i] * slope;
+                    acc[0][i] += gg;
+                    acc[1][i] += gg * ((v - mu[i]) * rs[i]);
+                }
+            }
+        }
+    }
+    block_column_reduce<2, NE>(acc, cpr, rpi, C, part);
+}
+
 template <typename TI, typename TG>
 __global__ __launch_bounds__(BN_THREADS) void rowbn_bwd_reduce_max_kernel(
     const TG *__restrict__ gy, const TI *__restrict__ x, const uint8_t *__restrict__ arg, long long Gp,
@@ -369,7 +428,7 @@ __global__ __launch_bounds__(BN_THREADS) void rowbn_bwd_reduce_max_kernel(
     for (int i = 0; i < NE; ++i) {
         acc[0][i] = 0.0f; acc[1][i] = 0.0f;
         const int c = chunk * NE + i;
-        mu[i] = mean[c]; rs[i] = rstd[c];
+        mu[i] = ld_mean(mean, c); rs[i] = ld_rstd(rstd, c);
         a[i] = (gamma ? gamma[c] : 1.0f) * rs[i];
         b[i] = beta ? beta[c] : 0.0f;
     }
@@ -419,8 +478,8 @@ __global__ __launch_bounds__(BN_THREADS) void rowbn_bwd_apply_kernel(
     float a[NE], b[NE], mu[NE], rs[NE], c1[NE], c2[NE];
 #pragma unroll
     for (int i = 0; i < NE; ++i) {
-        mu[i] = mean[col + i];
-        rs[i] = rstd[col + i];
+        mu[i] = ld_mean(mean, col + i);
+        rs[i] = ld_rstd(rstd, col + i);
         a[i] = (gamma ? gamma[col + i] : 1.0f) * rs[i];
         b[i] = beta ? beta[col + i] : 0.0f;
         c1[i] = c12[col + i];
@@ -517,11 +576,13 @@ extern "C" size_t tpg_rowbn_workspace_bytes(int C) {
 }
 
 extern "C" int tpg_rowbn_fwd(const void *x, int dtype_in, long long P, int K, int C, float eps, float momentum,
-                             int training, float *running_mean, float *running_var, const float *gamma,
-                             const float *beta, float slope, float *mean, float *rstd, void *y, int dtype_out,
-                             uint8_t *argmax, void *ws, int phase, void *stream) {
+                             int training, float *running_mean, float *running_var,
+                             long long *num_batches_tracked, const float *gamma, const float *beta, float slope,
+                             float *mean, float *rstd, void *y, int dtype_out, uint8_t *argmax, void *ws, int phase,
+                             void *stream) {
     if (P <= 0 || C <= 0 || K < 0 || K > 256 || (K > 0 && P % K)) return TPG_ERR_ARG;
-    if (!x || !mean || !rstd || !y || !ws || (K > 0 && !argmax)) return TPG_ERR_ARG;
+    if (!x || !y || !ws || (K > 0 && !argmax)) return TPG_ERR_ARG;
+    if (training ? (!mean || !rstd) : ((mean == nullptr) != (rstd == nullptr))) return TPG_ERR_ARG;
     if (!bn_dtype_ok(dtype_in) || !bn_dtype_ok(dtype_out) || !bn_shape_ok(dtype_in, dtype_out, C))
         return TPG_ERR_UNSUPPORTED;
     if ((reinterpret_cast<uintptr_t>(x) | reinterpret_cast<uintptr_t>(y)) & 15) return TPG_ERR_UNSUPPORTED;
@@ -536,12 +597,12 @@ extern "C" int tpg_rowbn_fwd(const void *x, int dtype_in, long long P, int K, in
             const __hip_bfloat16 *xx = static_cast<const __hip_bfloat16 *>(x);
             hipLaunchKernelGGL(rowbn_stats_kernel<__hip_bfloat16>, dim3(G), dim3(BN_THREADS), 0, st, xx, P, C, part);
             hipLaunchKernelGGL(rowbn_stats_finalize_kernel<__hip_bfloat16>, dim3((C + FIN_CH - 1) / FIN_CH), dim3(BN_THREADS), 0, st, xx,
-                               part, G, P, C, eps, momentum, running_mean, running_var, mean, rstd);
+                               part, G, P, C, eps, momentum, running_mean, running_var, num_batches_tracked, mean, rstd);
         } else {
             const float *xx = static_cast<const float *>(x);
             hipLaunchKernelGGL(rowbn_stats_kernel<float>, dim3(G), dim3(BN_THREADS), 0, st, xx, P, C, part);
             hipLaunchKernelGGL(rowbn_stats_finalize_kernel<float>, dim3((C + FIN_CH - 1) / FIN_CH), dim3(BN_THREADS), 0, st, xx, part, G,
-                               P, C, eps, momentum, running_mean, running_var, mean, rstd);
+                               P, C, eps, momentum, running_mean, running_var, num_batches_tracked, mean, rstd);
         }
     }  // eval mode: the caller has filled mean / rstd from the running statistics
     if (phase == TPG_BN_PHASE_STATS) {
@@ -572,11 +633,15 @@ extern "C" int tpg_rowbn_fwd(const void *x, int dtype_in, long long P, int K, in
 }
 
 extern "C" int tpg_rowbn_bwd(const void *gy, int dtype_g, const void *x, int dtype_in, const uint8_t *argmax,
-                             long long P, int K, int C, int training, const float *mean, const float *rstd,
-                             const float *gamma, const float *beta, float slope, float *dgamma, float *dbeta,
-                             void *dx, void *ws, int phase, void *stream) {
+                             const void *y, int dtype_y, long long P, int K, int C, int training,
+                             const float *mean, const float *rstd, const float *gamma, const float *beta,
+                             float slope, float *dgamma, float *dbeta, void *dx, void *ws, int phase,
+                             void *stream) {
     if (P <= 0 || C <= 0 || K < 0 || K > 256 || (K > 0 && P % K)) return TPG_ERR_ARG;
-    if (!gy || !x || !mean || !rstd || !dx || !ws || (K > 0 && !argmax)) return TPG_ERR_ARG;
+    if (!gy || !x || !dx || !ws || (K > 0 && !argmax)) return TPG_ERR_ARG;
+    if ((mean == nullptr) != (rstd == nullptr) || (training && !mean)) return TPG_ERR_ARG;
+    // the (gy, y) form of the max-variant sums needs y stored like gy, 16-byte aligned
+    const bool from_y = K > 0 && y && dtype_y == dtype_g && !(reinterpret_cast<uintptr_t>(y) & 15);
     if (!bn_dtype_ok(dtype_in) || !bn_dtype_ok(dtype_g) || !bn_shape_ok(dtype_in, dtype_g, C))
         return TPG_ERR_UNSUPPORTED;
     if ((reinterpret_cast<uintptr_t>(x) | reinterpret_cast<uintptr_t>(gy) | reinterpret_cast<uintptr_t>(dx)) & 15)
@@ -600,7 +665,11 @@ extern "C" int tpg_rowbn_bwd(const void *gy, int dtype_g, const void *x, int dty
         const TI *xx = static_cast<const TI *>(x);                                                          \
         const TG *gg = static_cast<const TG *>(gy);                                                         \
         if (!need_reduce) {                                                                                 \
-        } else if (K > 0)                                                                                   \
+        } else if (from_y)                                                                                  \
+            hipLaunchKernelGGL((rowbn_bwd_reduce_max_y_kernel<TI, TG>), dim3(G), dim3(BN_THREADS), 0, st, gg, \
+                               static_cast<const TG *>(y), xx, argmax, rows_g, K, C, mean, rstd, gamma, beta, \
+                               slope, part);                                                                \
+        else if (K > 0)                                                                                     \
             hipLaunchKernelGGL((rowbn_bwd_reduce_max_kernel<TI, TG>), dim3(G), dim3(BN_THREADS), 0, st, gg, xx, \
                                argmax, rows_g, K, C, mean, rstd, gamma, beta, slope, part);                 \
         else                                                                                                \

@@ -49,6 +49,43 @@ def _state_tensors(modules, optims):
     return ts
 
 
+def _flatten_state(modules, optims):
+    """Move every state tensor (parameters, buffers, optimizer state) into ONE flat buffer per
+    dtype, in place: the tensors keep their identity and become views.  The pre-step snapshot
+    is then one device copy per dtype instead of one per tensor (652 of them at cfg2).
+    Returns the flat buffers."""
+    tensors = []      # (tensor, is_parameter)
+    for m in modules:
+        tensors += [(p, True) for p in m.parameters()] + [(b, False) for b in m.buffers()]
+    for o in optims:
+        for st in o.state.values():
+            tensors += [(v, False) for v in st.values() if torch.is_tensor(v) and v.is_cuda]
+    by_dtype, seen = {}, set()
+    for t, is_param in tensors:
+        if id(t) in seen:
+            continue                      # a tensor registered twice moves once
+        seen.add(id(t))
+        by_dtype.setdefault(t.dtype, []).append((t, is_param))
+    flats = []
+    with torch.no_grad():
+        for dtype, ts in by_dtype.items():
+            align = 256 // ts[0][0].element_size()               # 256-byte aligned views
+            offs, total = [], 0
+            for t, _ in ts:
+                offs.append(total)
+                total += (t.numel() + align - 1) // align * align
+            flat = torch.zeros(max(total, 1), dtype=dtype, device=ts[0][0].device)
+            for (t, is_param), o in zip(ts, offs):
+                view = flat[o:o + t.numel()].view(t.shape)
+                view.copy_(t)
+                if is_param:
+                    t.data = view         # same Parameter object, storage = the flat buffer
+                else:
+                    t.set_(view)
+            flats.append(flat)
+    return flats
+
+
 class GraphedFluidStep:
     def __init__(self, sr_net, spatial_dis, tempo_dis, optims, opt, lowres_pos_lst, highres_pos_lst,
                  furthest_distance=1.0, amp_dtype=None, sync=None, warmup=2, segmented=None):
@@ -129,9 +166,11 @@ class GraphedFluidStep:
             edge_o, mask_o = G.body(torch.cat([low[f] for f in others], 0), torch.cat([low[f] for f in others], 0))
             pred_lst = [None] * self.T
             pred_lst[1] = padded_c
+            n_o = len(others)               # unbind: ONE stack in the backward instead of per-slice fills
+            edges = edge_o.reshape(n_o, self.B, *edge_o.shape[1:]).unbind(0)
+            masks = mask_o.reshape(n_o, self.B, *mask_o.shape[1:]).unbind(0)
             for i, f in enumerate(others):
-                sl = slice(i * self.B, (i + 1) * self.B)
-                _, padded, keep = G.expand_pos_static(low[f], edge_o[sl], mask_o[sl])
+                _, padded, keep = G.expand_pos_static(low[f], edges[i], masks[i])
                 viol = viol | ~keep
                 pred_lst[f] = padded.index_select(1, self.perm_f[i])
                 last_padded = padded
@@ -237,6 +276,22 @@ class GraphedFluidStep:
             if t.data_ptr() not in known:
                 t.zero_()
         torch.cuda.set_rng_state(rng, self.dev)
+        # all state into flat buffers BEFORE capture (addresses are baked into the graphs)
+        self._state = _flatten_state(modules, optims)
+        self._snap = [t.clone() for t in self._state]
+        # one more eager pass so that every pointer-keyed cache (spectral-norm descriptor tables,
+        # BatchNorm workspaces) is primed for the NEW addresses -- no host->device copy may happen
+        # while capturing -- then back to the snapshot once more
+        torch.cuda.synchronize(self.dev)
+        side.wait_stream(torch.cuda.current_stream(self.dev))
+        with torch.cuda.stream(side):
+            self._run_eager(True)
+        torch.cuda.current_stream(self.dev).wait_stream(side)
+        torch.cuda.synchronize(self.dev)
+        for d, t in zip(self._snap, self._state):
+            t.copy_(d)
+        torch.cuda.set_rng_state(rng, self.dev)
+        torch.cuda.synchronize(self.dev)
         self._graphs = {}
         for update_D in (True, False):
             graphs, pool = [], None
@@ -246,13 +301,17 @@ class GraphedFluidStep:
             for name, fn, reduce_module in segs:
                 g = torch.cuda.CUDAGraph()
                 with torch.cuda.graph(g, pool=pool):
-                    fn()
+                    try:
+                        fn()
+                    except BaseException:
+                        # leave the capture joinable: an unjoined side stream turns the original
+                        # error into "capturing stream has unjoined work" and poisons the stream
+                        torch.cuda.current_stream(self.dev).wait_stream(self.side)
+                        raise
                 pool = g.pool()
                 graphs.append((g, reduce_module))
             self._graphs[update_D] = graphs
             self._keep_alive = getattr(self, "_keep_alive", []) + [dict(self._keep)]
-        self._state = _state_tensors(modules, optims)
-        self._snap = [torch.empty_like(t) for t in self._state]
         torch.cuda.synchronize(self.dev)
 
     # ------------------------------------------------------------------ one training step
@@ -287,7 +346,8 @@ class GraphedFluidStep:
         self._host_i.copy_(torch.cat(perms))
         self._dev_f.copy_(self._host_f, non_blocking=True)
         self._dev_i.copy_(self._host_i, non_blocking=True)
-        torch._foreach_copy_(self._snap, self._state)                 # pre-step snapshot (18 MB)
+        for d, t in zip(self._snap, self._state):                       # pre-step snapshot (18 MB, one copy
+            d.copy_(t)                                                  # per dtype: the state is flat)
         for g, reduce_module in self._graphs[update_D]:
             g.replay()
             if reduce_module is not None:
@@ -295,7 +355,8 @@ class GraphedFluidStep:
         out = torch.cat([self.report, self.viol]).cpu().tolist()        # the step's one host sync
         if out[6] != 0.0:
             # not the static regime: put everything back and take the general path with the same draws
-            torch._foreach_copy_(self._state, self._snap)
+            for d, t in zip(self._snap, self._state):
+                t.copy_(d)
             np.random.set_state(np_state)
             torch.set_rng_state(cpu_rng)
             torch.cuda.set_rng_state(cuda_rng, self.dev)

@@ -115,19 +115,21 @@ class _TallLinear(torch.autograd.Function):
     S*4..16 workgroups and finish in a few tens of us.  Partial products are summed in fp32."""
 
     @staticmethod
-    def forward(ctx, x, w, dtype):
+    def forward(ctx, x, w, bias, dtype):
         xd = x.to(dtype)
         wd = w.to(dtype)
         ctx.save_for_backward(xd, wd)
-        ctx.w_dtype = w.dtype
-        ctx.x_dtype = x.dtype
-        return xd @ wd.t()
+        ctx.w_dtype, ctx.x_dtype = w.dtype, x.dtype
+        ctx.b_dtype = None if bias is None else bias.dtype
+        if bias is None:
+            return xd @ wd.t()
+        return torch.addmm(bias.to(dtype), xd, wd.t())            # bias in the GEMM epilogue
 
     @staticmethod
     def backward(ctx, gy):
         xd, wd = ctx.saved_tensors
         gy = gy.to(xd.dtype)
-        dx = dw = None
+        dx = dw = db = None
         if ctx.needs_input_grad[0]:
             dx = (gy @ wd).to(ctx.x_dtype)
         if ctx.needs_input_grad[1]:
@@ -136,14 +138,33 @@ class _TallLinear(torch.autograd.Function):
             if S > 1:
                 rows = P // S
                 head = S * rows
-                part = torch.bmm(gy[:head].view(S, rows, -1).transpose(1, 2), xd[:head].view(S, rows, -1))
-                dw = part.float().sum(0)
+                dw = _mm_f32(torch.bmm, gy[:head].view(S, rows, -1).transpose(1, 2),
+                             xd[:head].view(S, rows, -1)).sum(0)
                 if head < P:
-                    dw = dw + (gy[head:].t() @ xd[head:]).float()
+                    dw = dw + _mm_f32(torch.mm, gy[head:].t(), xd[head:])
             else:
-                dw = (gy.t() @ xd).float()
+                dw = _mm_f32(torch.mm, gy.t(), xd)
             dw = dw.to(ctx.w_dtype)
-        return dx, dw, None
+        if ctx.b_dtype is not None and ctx.needs_input_grad[2]:
+            db = gy.sum(0, dtype=torch.float32).to(ctx.b_dtype)
+        return dx, dw, db, None
+
+
+_F32_OUT = [None]     # does this torch build take out_dtype on mm / bmm?  (probed once, on the device)
+
+
+def _mm_f32(fn, a, b):
+    """fn(a, b) accumulated AND stored in fp32 (no bf16 rounding of the split-K partials, no
+    separate cast kernel) where the build offers out_dtype; else the product cast to fp32."""
+    if a.dtype == torch.float32:
+        return fn(a, b)
+    if _F32_OUT[0] is None:
+        try:
+            fn(a, b, out_dtype=torch.float32)
+            _F32_OUT[0] = True
+        except (TypeError, RuntimeError, NotImplementedError):
+            _F32_OUT[0] = False
+    return fn(a, b, out_dtype=torch.float32) if _F32_OUT[0] else fn(a, b).float()
 
 
 def _split_k(P, cout, cin):
@@ -165,9 +186,7 @@ def rows_matmul(x, w, bias=None):
         dtype = torch.get_autocast_gpu_dtype() if torch.is_autocast_enabled() else x.dtype
         if dtype in (torch.float32, torch.bfloat16, torch.float16):
             with torch.autocast(device_type="cuda", enabled=False):
-                y = _TallLinear.apply(x.reshape(P, x.shape[-1]), w, dtype)
-                if bias is not None:
-                    y = y + bias.to(y.dtype)
+                y = _TallLinear.apply(x.reshape(P, x.shape[-1]), w, bias, dtype)
             return y.view(*lead, w.shape[0])
     return F.linear(x, w, bias)
 

@@ -271,14 +271,15 @@ class HipBackend:
         return ws
 
     def rowbn_fwd(self, x, K, eps, momentum, training, running_mean, running_var, gamma, beta, slope,
-                  mean, rstd, out_dtype):
+                  mean, rstd, out_dtype, num_batches_tracked=None):
         P, Cc = x.shape
         rows = P // K if K else P
         y = torch.empty((rows, Cc), dtype=out_dtype, device=x.device)
         arg = torch.empty((rows, Cc), dtype=torch.uint8, device=x.device) if K else None
         ws = self._bn_ws(x, Cc)
         args = (_ptr(x), _DTYPE_CODE[x.dtype], P, K, Cc, float(eps), float(momentum), int(training),
-                _ptr(running_mean), _ptr(running_var), _ptr(gamma), _ptr(beta), float(slope), _ptr(mean),
+                _ptr(running_mean), _ptr(running_var), _ptr(num_batches_tracked), _ptr(gamma), _ptr(beta),
+                float(slope), _ptr(mean),
                 _ptr(rstd), _ptr(y), _DTYPE_CODE[out_dtype], _ptr(arg), _ptr(ws))
         b_stats = x.element_size() * P * Cc
         b_apply = x.element_size() * P * Cc + y.element_size() * rows * Cc + (rows * Cc if K else 0)
@@ -290,17 +291,21 @@ class HipBackend:
             self._call("tpg_rowbn_fwd", "rowbn_fwd_apply_max" if K else "rowbn_fwd_apply", b_apply, x, *args, 2)
         return y, arg
 
-    def rowbn_bwd(self, gy, x, arg, K, training, mean, rstd, gamma, beta, slope, need_affine):
+    def rowbn_bwd(self, gy, x, arg, K, training, mean, rstd, gamma, beta, slope, need_affine, y=None):
         P, Cc = x.shape
         dx = torch.empty_like(x)
         dgamma = torch.empty(Cc, dtype=torch.float32, device=x.device) if need_affine else None
         dbeta = torch.empty(Cc, dtype=torch.float32, device=x.device) if need_affine else None
         ws = self._bn_ws(x, Cc)
-        args = (_ptr(gy), _DTYPE_CODE[gy.dtype], _ptr(x), _DTYPE_CODE[x.dtype], _ptr(arg), P, K, Cc,
+        if y is not None and (not K or y.dtype != gy.dtype):
+            y = None
+        args = (_ptr(gy), _DTYPE_CODE[gy.dtype], _ptr(x), _DTYPE_CODE[x.dtype], _ptr(arg), _ptr(y),
+                _DTYPE_CODE[y.dtype] if y is not None else 0, P, K, Cc,
                 int(training), _ptr(mean), _ptr(rstd), _ptr(gamma), _ptr(beta), float(slope), _ptr(dgamma),
                 _ptr(dbeta), _ptr(dx), _ptr(ws))
         b_gy = gy.element_size() * gy.numel() + (gy.numel() if K else 0)
-        b_reduce = b_gy + x.element_size() * (gy.numel() if K else P * Cc)
+        b_reduce = (2 * gy.element_size() * gy.numel() if y is not None
+                    else b_gy + x.element_size() * (gy.numel() if K else P * Cc))
         b_apply = b_gy + 2 * x.element_size() * P * Cc
         if _timer is None:
             self._call("tpg_rowbn_bwd", "rowbn_bwd", b_reduce + b_apply, x, *args, 0)
@@ -648,61 +653,68 @@ def row_combine(U, QE, idx, mode, slope=0.2, out_dtype=None):
 # ------------------------------------------------ fused BatchNorm + LeakyReLU (+ max over K)
 class _RowBNAct(torch.autograd.Function):
     @staticmethod
-    def forward(ctx, x, gamma, beta, running_mean, running_var, training, momentum, eps, slope, K, out_dtype):
+    def forward(ctx, x, gamma, beta, running_mean, running_var, training, momentum, eps, slope, K, out_dtype,
+                num_batches_tracked):
         be = backend_for(x)
         C_ = x.shape[1]
         if training:
             mean = torch.empty(C_, dtype=torch.float32, device=x.device)
             rstd = torch.empty(C_, dtype=torch.float32, device=x.device)
+        elif running_mean is None:                  # identity statistics: activation (+max) only
+            mean = rstd = None
         else:
             mean = running_mean.float().contiguous()
             rstd = torch.rsqrt(running_var.float() + eps)
         y, arg = be.rowbn_fwd(x, K, eps, momentum, training, running_mean if training else None,
-                              running_var if training else None, gamma, beta, slope, mean, rstd, out_dtype)
-        ctx.save_for_backward(x, gamma, beta, mean, rstd, arg)
+                              running_var if training else None, gamma, beta, slope, mean, rstd, out_dtype,
+                              num_batches_tracked if training else None)
+        # K > 0: the (small) output doubles as the backward's source of the arg-max pre-activations
+        ctx.save_for_backward(x, gamma, beta, mean, rstd, arg, y if K else None)
         ctx.cfg = (training, slope, K)
         return y
 
     @staticmethod
     def backward(ctx, gy):
-        x, gamma, beta, mean, rstd, arg = ctx.saved_tensors
+        x, gamma, beta, mean, rstd, arg, y = ctx.saved_tensors
         training, slope, K = ctx.cfg
         gy = gy.contiguous()
         if gy.dtype not in _DTYPE_CODE:
             gy = gy.float()
         need_affine = gamma is not None and (ctx.needs_input_grad[1] or ctx.needs_input_grad[2])
         dx, dgamma, dbeta = backend_for(x).rowbn_bwd(gy, x, arg, K, training, mean, rstd, gamma, beta, slope,
-                                                    need_affine)
-        return dx, dgamma, dbeta, None, None, None, None, None, None, None, None
+                                                    need_affine, y)
+        return dx, dgamma, dbeta, None, None, None, None, None, None, None, None, None
 
 
 def row_bn_act(x, gamma, beta, running_mean, running_var, training, momentum, eps, slope=1.0, K=0,
-               out_dtype=None):
+               out_dtype=None, num_batches_tracked=None):
     """Fused BatchNorm (+LeakyReLU, + max over groups of K rows) on rows (include/tpgan_ops.h).
 
     x (P,C) fp32/bf16 -> (P,C) or (P/K,C).  slope: 1.0 = no activation, 0.0 = ReLU.  In training mode
-    the running statistics are updated in place (momentum, unbiased variance) like nn.BatchNorm."""
+    the running statistics are updated in place (momentum, unbiased variance) like nn.BatchNorm,
+    and `num_batches_tracked` (int64 scalar tensor, optional) is incremented by the same launch.
+    Eval mode with running_mean = running_var = None means identity statistics."""
     _need(x.dim() == 2 and x.dtype in _DTYPE_CODE, "x must be (P,C) fp32/bf16")
     _need(K == 0 or (0 < K <= 256 and x.shape[0] % K == 0), "K must divide the row count (<= 256)")
     out_dtype = out_dtype or x.dtype
     ne = 4 if (x.dtype == torch.float32 and out_dtype == torch.float32) else 8
     _need(x.shape[1] % ne == 0 and x.shape[1] <= 1024, f"channels must be a multiple of {ne}, <= 1024")
     if not training:
-        _need(running_mean is not None and running_var is not None, "eval mode needs running statistics")
+        _need((running_mean is None) == (running_var is None), "eval mode: both running statistics or neither")
+    if num_batches_tracked is not None:
+        _need(num_batches_tracked.dtype == torch.int64 and num_batches_tracked.numel() == 1
+              and num_batches_tracked.device == x.device, "num_batches_tracked must be an int64 scalar on x's device")
     g = None if gamma is None else gamma.float().contiguous()
     b = None if beta is None else beta.float().contiguous()
     return _RowBNAct.apply(x.contiguous(), g, b, running_mean, running_var, bool(training), float(momentum),
-                           float(eps), float(slope), int(K), out_dtype)
+                           float(eps), float(slope), int(K), out_dtype, num_batches_tracked)
 
 
 def row_act_max(x, slope, K, out_dtype=None):
     """max over each group of K consecutive rows of LeakyReLU(x): the [activation -> max over
     the k neighbours] tail of an EdgeConv MLP (gcn_lib/pointnet/gcn.py:211) in one pass, with a
     one-pass backward (same kernels as row_bn_act with identity statistics)."""
-    C_ = x.shape[1]
-    zeros = torch.zeros(C_, dtype=torch.float32, device=x.device)
-    ones = torch.ones(C_, dtype=torch.float32, device=x.device)
-    return row_bn_act(x, None, None, zeros, ones, False, 0.0, 0.0, slope, K, out_dtype)
+    return row_bn_act(x, None, None, None, None, False, 0.0, 0.0, slope, K, out_dtype)
 
 
 # ---------------------------------------------------------------------- fused spectral norm

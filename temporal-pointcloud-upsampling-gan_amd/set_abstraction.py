@@ -149,14 +149,17 @@ def bn_act_rows(bn, x, slope, K=0):
     (ops.row_bn_act, csrc/rowbn.hip); module state handled like nn.BatchNorm's own forward."""
     training = bn.training or (bn.running_mean is None and bn.running_var is None)
     momentum = 0.0 if bn.momentum is None else bn.momentum
+    nbt = None
     if bn.training and bn.track_running_stats and bn.num_batches_tracked is not None:
-        bn.num_batches_tracked.add_(1)
-        if bn.momentum is None:
+        if bn.momentum is None:                    # cumulative average: the factor is needed on the host
+            bn.num_batches_tracked.add_(1)
             momentum = 1.0 / float(bn.num_batches_tracked)
+        else:
+            nbt = bn.num_batches_tracked           # incremented by the statistics kernel itself
     track = bn.track_running_stats and bn.running_mean is not None
     return ops.row_bn_act(x, bn.weight, bn.bias, bn.running_mean if track else None,
                           bn.running_var if track else None, training, momentum, bn.eps, slope, K,
-                          out_dtype=amp_dtype(x))
+                          out_dtype=amp_dtype(x), num_batches_tracked=nbt)
 
 
 def mlp_tail_rows(layers, x, reduce_max=False):
@@ -348,7 +351,8 @@ class _PointnetSAModuleBase(nn.Module):
                 Qs.append(rows_matmul(new_xyz[sl], W[:, :3]))
         y = ops.row_combine(torch.cat(Us, 0), torch.cat(Qs, 0), idx, ops.ROW_SUB, out_dtype=amp_dtype(xyz))
         tail = list(mlp)[1:]
-        feats = [mlp_tail_rows(tail, y[t * B:(t + 1) * B], reduce_max=True) for t in range(T)]
+        # unbind, not T slices: its backward is ONE stack instead of T x (zero-fill + copy + add)
+        feats = [mlp_tail_rows(tail, yt, reduce_max=True) for yt in y.view(T, B, *y.shape[1:]).unbind(0)]
         return [new_xyz[t * B:(t + 1) * B] for t in range(T)], feats
 
     def forward(self, xyz, features):

@@ -322,16 +322,19 @@ def test_rowbn_matches_oracle(hip, training, P, K, C, din, dout):
     if din == "bf16":
         x = _bf16_round(x)
     gamma = rng.uniform(0.5, 1.5, C).astype(np.float32)
+    gamma[::5] = 0.05                      # |beta| > 4|gamma| there: the backward's gather branch
     beta = rng.standard_normal(C).astype(np.float32)
     rm0, rv0 = rng.standard_normal(C).astype(np.float32), rng.uniform(0.5, 2.0, C).astype(np.float32)
     slope, eps, mom = 0.01, 1e-5, 0.1
+    nbt = torch.full((), 7, dtype=torch.int64, device="cuda")
     mean, rstd = torch.empty(C, device="cuda"), torch.empty(C, device="cuda")
     rm, rv = dev(rm0.copy()), dev(rv0.copy())
     if not training:
         mean, rstd = dev(rm0.copy()), torch.rsqrt(dev(rv0.copy()) + eps)
     xd = dev(x).to(tdt[din])
     y, arg = hip.rowbn_fwd(xd, K, eps, mom, training, rm if training else None, rv if training else None,
-                           dev(gamma), dev(beta), slope, mean, rstd, tdt[dout])
+                           dev(gamma), dev(beta), slope, mean, rstd, tdt[dout], nbt if training else None)
+    assert int(nbt) == (8 if training else 7)          # incremented by the statistics launch
     ry, rmean, rrstd, rarg = R.rowbn_fwd(x, K, eps, gamma, beta, slope, training,
                                          None if training else rm0, None if training else 1 / np.sqrt(rv0 + eps))
     otol = 1e-5 if dout == "f32" else 8e-3
@@ -355,9 +358,23 @@ def test_rowbn_matches_oracle(hip, training, P, K, C, din, dout):
     assert np.abs(db.cpu().numpy() - rdb).max() <= 2e-5 * max(1.0, np.abs(rdb).max())
     assert np.abs(dg.cpu().numpy() - rdg).max() <= 2e-5 * max(1.0, np.abs(rdg).max())
     assert np.abs(dx.float().cpu().numpy() - rdx).max() <= gtol * max(1.0, np.abs(rdx).max())
-    if K:   # the arg-max really points at a maximal element
-        yk = np.where(True, ry, ry)  # (rows, C) maxima
-        assert (arg.cpu().numpy() < K).all() and yk.shape == (rows, C)
+    if K:
+        assert (arg.cpu().numpy() < K).all()
+        # the same sums taken from (gy, y): arg-max pre-activations recovered from the output
+        dx2, dg2, db2 = hip.rowbn_bwd(dev(gy).to(tdt[dout]), xd, arg, K, training, mean, rstd, dev(gamma),
+                                      dev(beta), slope, True, y)
+        ytol = 2e-5 if dout == "f32" else 1e-2
+        assert np.abs(db2.cpu().numpy() - rdb).max() <= 2e-5 * max(1.0, np.abs(rdb).max())
+        assert np.abs(dg2.cpu().numpy() - rdg).max() <= ytol * max(1.0, np.abs(rdg).max())
+        assert np.abs(dx2.float().cpu().numpy() - rdx).max() <= max(gtol, ytol) * max(1.0, np.abs(rdx).max())
+
+
+def test_rowbn_identity_statistics(hip):
+    """Eval mode without statistics = activation (+max) only."""
+    x = torch.randn(2 * 64 * 16, 64, device="cuda")
+    y, arg = hip.rowbn_fwd(x, 16, 0.0, 0.0, False, None, None, None, None, 0.2, None, None, torch.float32)
+    ref = torch.nn.functional.leaky_relu(x.view(128, 16, 64), 0.2).max(1)[0]
+    assert torch.equal(y, ref)
 
 
 def test_rowbn_statistics_are_bitwise_reproducible(hip):

@@ -1,0 +1,85 @@
+"""Which lines of the step launch the SMALL kernels?  (torch.profiler, eager step, GPU box)
+
+Every aten op that launches a kernel is attributed to the innermost frame inside this repo
+(forward) or to the autograd node that ran it (backward), and counted.  Output: one table,
+sorted by launches per step -- the input for deciding what to fuse next.
+
+    python tools/kernel_sources.py [max_us]      # only kernels shorter than max_us (default 8)
+"""
+import collections
+import importlib.util
+import os
+import sys
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+import numpy as np
+import torch
+from torch.profiler import ProfilerActivity, profile
+
+spec = importlib.util.spec_from_file_location("bench", os.path.join(ROOT, "bench.py"))
+b = importlib.util.module_from_spec(spec)
+argv, sys.argv = sys.argv, ["bench.py"]
+spec.loader.exec_module(b)
+max_us = float(argv[1]) if len(argv) > 1 else 8.0
+
+torch.backends.cudnn.enabled = False
+dev = torch.device("cuda", 0)
+np.random.seed(0)
+models = b.build(dev, capturable=True)
+clips = [b.fluid_clip(8, 4096, 8, 3, seed=s, device=dev) for s in range(2)]
+from tpgan_amd.gan_step_graph import GraphedFluidStep
+G, Ds, Dt, opts = models
+step = GraphedFluidStep(G, Ds, Dt, opts, b.OPT, clips[0][0], clips[0][1], 1.0, torch.bfloat16, None)
+step._load(*clips[1])
+step._run_eager(True)                                       # the body the graph captured, run eagerly
+torch.cuda.synchronize()
+with profile(activities=[ProfilerActivity.CPU, ProfilerActivity.CUDA], with_stack=True) as prof:
+    step._run_eager(True)
+    torch.cuda.synchronize()
+
+
+def own_frame(evt):
+    p = evt
+    while p is not None:                       # the Python stack hangs on the outermost op
+        for fr in (p.stack or []):
+            if ("temporal-pointcloud" in fr or "tpgan_amd" in fr) and "site-packages" not in fr:
+                return fr.replace(ROOT + "/", "").replace("temporal-pointcloud-upsampling-gan_amd/", "")
+        p = p.cpu_parent
+    return None
+
+
+def autograd_node(evt):
+    p = evt
+    while p is not None:
+        if p.name.startswith("autograd::engine::evaluate_function: "):
+            return "bwd " + p.name.split(": ", 1)[1]
+        p = p.cpu_parent
+    return None
+
+
+count = collections.Counter()
+time_us = collections.Counter()
+for evt in prof.events():
+    kernels = getattr(evt, "kernels", None)
+    if not kernels:
+        continue
+    # leaf-most op only: skip if a child op also owns kernels
+    if any(getattr(c, "kernels", None) for c in evt.cpu_children):
+        continue
+    for k in kernels:
+        dur = k.duration
+        if dur > max_us:
+            continue
+        where = autograd_node(evt) or own_frame(evt) or "?"
+        key = (evt.name, where)
+        count[key] += 1
+        time_us[key] += dur
+total = sum(count.values())
+print(f"{total} kernels shorter than {max_us} us in one eager step, {sum(time_us.values()) / 1e3:.2f} ms")
+for key, n in count.most_common(70):
+    print(f"{n:5d}  {time_us[key] / 1e3:6.3f} ms  {key[0]:28s} {key[1]}")
+if os.environ.get("KS_DUMP_STACK"):
+    for evt in prof.events():
+        if getattr(evt, "kernels", None) and evt.stack:
+            print(evt.name, evt.stack[:12]); break
