@@ -142,7 +142,8 @@ int tpg_rowcombine_bwd(const void *gout, const int32_t *idx, const int32_t *offs
  * *num_batches_tracked (may be NULL) is incremented, as nn.BatchNorm's forward does.
  * training == 0: mean / rstd are inputs (the caller derives them from the running statistics);
  * both NULL = identity statistics (mean 0, rstd 1: a pure activation [+ max]).
- * ws: tpg_rowbn_workspace_bytes(C) bytes of scratch.  gamma / beta may be NULL (1 / 0).
+ * ws: tpg_rowbn_workspace_bytes(C) bytes of scratch, 16-byte aligned, not shared by launches that
+ * may run concurrently.  gamma / beta may be NULL (1 / 0).
  * phase: TPG_BN_PHASE_ALL, or the reduction part / the streaming part alone (two calls with the
  * same arguments and workspace = one ALL call; lets a profiler time each kernel by itself). */
 #define TPG_BN_PHASE_ALL 0

@@ -11,13 +11,24 @@
 //   backward: g = gy * lrelu'(a*x+b);  dbeta = sum g, dgamma = sum g*xhat   (1 read of x,gy)
 //             dx = a * (g - dbeta/P - xhat*dgamma/P)                       (1 read, 1 write)
 //
-// i.e. 2+3 streaming passes at HBM rate instead of PyTorch's BatchNorm (stats + transform),
-// LeakyReLU, max-reduce and their three backward kernels.  Rows are 16-byte vectors per lane
-// (fp32 or bf16 storage, fp32 arithmetic); column sums use per-thread register accumulators
-// over a grid-stride of rows, one LDS tree per workgroup, and a deterministic two-stage
-// reduction (per-workgroup partials -> one finalize workgroup in fp64), so statistics are
-// bitwise reproducible run to run and there are no float atomics.  Sums are taken about a
-// per-channel pivot (the first row) to keep E[x^2]-E[x]^2 well conditioned.
+// i.e. 2+2 launches and 2+3 streaming passes instead of PyTorch's BatchNorm (stats + transform),
+// LeakyReLU, max-reduce and their three backward kernels.
+//
+// What the kernels are built around (measured on MI355X, tools/tune_rowbn.py):
+//   * reductions are two launches: workgroups write per-channel partials, a small finalize
+//     kernel (one workgroup per 4 channels) sums them in fixed order in fp64 -> bitwise
+//     reproducible, no float atomics.  (Letting the last-arriving workgroup finish the sum saves
+//     the ~5 us launch but serialises G x 2C dependent-latency loads on one CU: 35-90 us
+//     measured, against 13 us for the pair of launches.)
+//   * few fat workgroups beat many thin ones (workgroup dispatch + the per-channel constant
+//     prologue dominate thin ones): grids are sized to ~1-2 workgroups per CU and each thread
+//     walks many rows;
+//   * the row walk is software-pipelined: the 16-byte loads of the next U rows are in flight
+//     while the current U rows are computed (bf16 unpack, FMA, select: ~50 VALU ops per 16 B
+//     would otherwise alternate with the memory latency instead of hiding it).
+// Rows are 16-byte vectors per lane (fp32 or bf16 storage, fp32 arithmetic); a thread owns one
+// column chunk, so per-channel constants stay in registers.  Sums are taken about a per-channel
+// pivot (the first row) to keep E[x^2]-E[x]^2 well conditioned.
 #include <hip/hip_bf16.h>
 
 #include "tpg_common.hpp"
@@ -25,16 +36,56 @@
 namespace {
 
 constexpr int BN_THREADS = 256;
-constexpr int BN_MAX_BLOCKS = 512;   // partial rows per reduction (2 workgroups per CU)
 
-// ---- 16-byte row chunks <-> NE floats (same helpers as rowgather.hip) ----------------------
-template <typename T, int NE> struct BnIO;
-template <int NE> struct BnIO<float, NE> {
-    static __device__ __forceinline__ void load(const float *p, float (&v)[NE]) {
+// Tunables (tools/tune_rowbn.py builds variants with -D and times them on the GPU)
+#ifndef TPG_BN_MAX_BLOCKS
+#define TPG_BN_MAX_BLOCKS 256  // most workgroups (= partial rows) of a reduction launch
+#endif
+#ifndef TPG_BN_STATS_ROWS
+#define TPG_BN_STATS_ROWS 8    // rows per thread a reduction launch aims at (before the cap binds)
+#endif
+#ifndef TPG_BN_YRED_ROWS
+#define TPG_BN_YRED_ROWS 4     // same for the small (gy, y) reduction of the max variant
+#endif
+#ifndef TPG_BN_STATS_U
+#define TPG_BN_STATS_U 8       // rows per pipeline stage of the (one-tensor, read-only) statistics walk
+#endif
+#ifndef TPG_BN_APPLY_CAP
+#define TPG_BN_APPLY_CAP 256   // most workgroups of a streaming (apply) launch: one per CU
+#endif
+#ifndef TPG_BN_APPLY_ROWS
+#define TPG_BN_APPLY_ROWS 8    // rows per thread a streaming launch aims at
+#endif
+#ifndef TPG_BN_GROUP_CAP
+#define TPG_BN_GROUP_CAP 512   // most workgroups of a max-variant launch (one thread walks whole groups)
+#endif
+#ifndef TPG_BN_UNROLL
+#define TPG_BN_UNROLL 4        // rows per pipeline stage, one-tensor kernels
+#endif
+#ifndef TPG_BN_BWD_U
+#define TPG_BN_BWD_U 2         // rows per pipeline stage, two-tensor kernels
+#endif
+constexpr int BN_MAX_BLOCKS = TPG_BN_MAX_BLOCKS;
+constexpr int BN_UNROLL = TPG_BN_UNROLL;
+constexpr int BN_BWD_U = TPG_BN_BWD_U;
+constexpr int WS_HEAD = 16;    // floats reserved at the start of the workspace
+
+__device__ __forceinline__ float lrelu_f(float z, float slope) { return z > 0.0f ? z : z * slope; }
+// pre-activation, written ONCE so that forward and backward see the same sign
+__device__ __forceinline__ float bn_z(float v, float mu, float a, float beta) { return (v - mu) * a + beta; }
+
+// ---- a row chunk of NE channels held as raw 16-byte registers until it is used --------------
+template <typename T, int NE> struct Chunk;
+template <int NE> struct Chunk<float, NE> {
+    float4 r[NE / 4];
+    __device__ __forceinline__ void load(const float *p) {
+#pragma unroll
+        for (int i = 0; i < NE / 4; ++i) r[i] = reinterpret_cast<const float4 *>(p)[i];
+    }
+    __device__ __forceinline__ void unpack(float (&v)[NE]) const {
 #pragma unroll
         for (int i = 0; i < NE / 4; ++i) {
-            const float4 x = reinterpret_cast<const float4 *>(p)[i];
-            v[4 * i] = x.x; v[4 * i + 1] = x.y; v[4 * i + 2] = x.z; v[4 * i + 3] = x.w;
+            v[4 * i] = r[i].x; v[4 * i + 1] = r[i].y; v[4 * i + 2] = r[i].z; v[4 * i + 3] = r[i].w;
         }
     }
     static __device__ __forceinline__ void store(float *p, const float (&v)[NE]) {
@@ -44,10 +95,11 @@ template <int NE> struct BnIO<float, NE> {
     }
     static __device__ __forceinline__ float one(const float *p) { return *p; }
 };
-template <> struct BnIO<__hip_bfloat16, 8> {
-    static __device__ __forceinline__ void load(const __hip_bfloat16 *p, float (&v)[8]) {
-        const uint4 x = *reinterpret_cast<const uint4 *>(p);
-        const unsigned w[4] = {x.x, x.y, x.z, x.w};
+template <> struct Chunk<__hip_bfloat16, 8> {
+    uint4 r;
+    __device__ __forceinline__ void load(const __hip_bfloat16 *p) { r = *reinterpret_cast<const uint4 *>(p); }
+    __device__ __forceinline__ void unpack(float (&v)[8]) const {
+        const unsigned w[4] = {r.x, r.y, r.z, r.w};
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
             v[2 * i] = __uint_as_float(w[i] << 16);
@@ -71,19 +123,61 @@ template <> struct BnIO<__hip_bfloat16, 8> {
 };
 template <typename T> struct BnElems { static constexpr int NE = sizeof(T) == 2 ? 8 : 4; };
 
-__device__ __forceinline__ float lrelu_f(float z, float slope) { return z > 0.0f ? z : z * slope; }
-// NULL statistics = identity (mean 0, rstd 1)
-__device__ __forceinline__ float ld_mean(const float *mean, int c) { return mean ? mean[c] : 0.0f; }
-__device__ __forceinline__ float ld_rstd(const float *rstd, int c) { return rstd ? rstd[c] : 1.0f; }
-// pre-activation, written ONCE so that forward and backward see the same sign
-__device__ __forceinline__ float bn_z(float v, float mu, float a, float beta) { return (v - mu) * a + beta; }
+// NE per-channel constants starting at channel `col` (a multiple of NE): vector loads when the
+// array is 16-byte aligned, `dflt` when the array is absent.  All branches are wave-uniform.
+template <int NE>
+__device__ __forceinline__ void ld_consts(const float *__restrict__ p, int col, float dflt, float (&out)[NE]) {
+    if (p == nullptr) {
+#pragma unroll
+        for (int i = 0; i < NE; ++i) out[i] = dflt;
+    } else if ((reinterpret_cast<uintptr_t>(p) & 15) == 0) {
+#pragma unroll
+        for (int i = 0; i < NE / 4; ++i) {
+            const float4 t = reinterpret_cast<const float4 *>(p + col)[i];
+            out[4 * i] = t.x; out[4 * i + 1] = t.y; out[4 * i + 2] = t.z; out[4 * i + 3] = t.w;
+        }
+    } else {
+#pragma unroll
+        for (int i = 0; i < NE; ++i) out[i] = p[col + i];
+    }
+}
 
-// Thread layout shared by every kernel here: a thread owns ONE 16-byte column chunk
-// (chunk = tid % cpr) and walks rows rsub, rsub + rpi, ... (rsub = tid / cpr, rpi = 256 / cpr rows
-// per workgroup iteration), so per-channel constants are loaded once and stay in registers.
-//
-// Column reduction of NQ quantities per channel: every thread has acc[NQ][NE] for its chunk;
-// all 256 threads take part: output o = (q, i, chunk) sums its rpi partners from LDS.
+// ---- software-pipelined walk over the rows r0, r0+step, ... < P ------------------------------
+// Stage: the raw registers of U rows.  load(stage, u, row) issues the global loads of one row,
+// proc(stage, u, row) consumes them.  The loads of stage n+1 are issued before stage n is
+// processed, so 2U rows of loads are in flight per thread.
+template <int U, typename Stage, typename Load, typename Proc>
+__device__ __forceinline__ void pipelined_rows(long long r, long long step, long long P, Load load, Proc proc) {
+    Stage cur, nxt;
+    bool have = r + (U - 1) * step < P;
+    if (have) {
+#pragma unroll
+        for (int u = 0; u < U; ++u) load(cur, u, r + u * step);
+    }
+    while (have) {
+        const long long rn = r + U * step;
+        const bool have_n = rn + (U - 1) * step < P;
+        if (have_n) {
+#pragma unroll
+            for (int u = 0; u < U; ++u) load(nxt, u, rn + u * step);
+        }
+#pragma unroll
+        for (int u = 0; u < U; ++u) proc(cur, u, r + u * step);
+        cur = nxt;
+        r = rn;
+        have = have_n;
+    }
+    for (; r < P; r += step) {
+        load(cur, 0, r);
+        proc(cur, 0, r);
+    }
+}
+
+// ---- block-level column reduction + "last workgroup finishes" ---------------------------------
+// Thread layout shared by every kernel here: a thread owns ONE column chunk (chunk = tid % cpr)
+// and walks rows rsub, rsub + rpi, ... (rsub = tid / cpr, rpi = 256 / cpr rows per workgroup
+// iteration).  Column reduction of NQ quantities per channel: every thread has acc[NQ][NE] for
+// its chunk; output o = (q, i, chunk) sums its rpi partners from LDS.
 template <int NQ, int NE>
 __device__ __forceinline__ void block_column_reduce(float (&acc)[NQ][NE], int cpr, int rpi, int C,
                                                     float *__restrict__ part) {
@@ -103,51 +197,6 @@ __device__ __forceinline__ void block_column_reduce(float (&acc)[NQ][NE], int cp
         const int q = qi / NE, i = qi - q * NE;
         part[((size_t)blockIdx.x * NQ + q) * C + chunk * NE + i] = s;
     }
-}
-
-constexpr int BN_UNROLL = 4;  // independent 16-byte loads in flight per thread
-
-// ------------------------------------------------------------------ forward statistics
-template <typename T>
-__global__ __launch_bounds__(BN_THREADS) void rowbn_stats_kernel(const T *__restrict__ x, long long P, int C,
-                                                                 float *__restrict__ part) {
-    constexpr int NE = BnElems<T>::NE;
-    const int cpr = C / NE, rpi = BN_THREADS / cpr;  // chunks per row, rows per iteration
-    const int tid = threadIdx.x;
-    const int chunk = tid % cpr, rsub = tid / cpr;
-    float acc[2][NE];
-    float piv[NE];
-#pragma unroll
-    for (int i = 0; i < NE; ++i) { acc[0][i] = 0.0f; acc[1][i] = 0.0f; }
-    if (rsub < rpi) {
-        BnIO<T, NE>::load(x + chunk * NE, piv);  // pivot = first row
-        const long long step = (long long)gridDim.x * rpi;
-        long long r = (long long)blockIdx.x * rpi + rsub;
-        for (; r + (BN_UNROLL - 1) * step < P; r += BN_UNROLL * step) {
-            float v[BN_UNROLL][NE];
-#pragma unroll
-            for (int u = 0; u < BN_UNROLL; ++u) BnIO<T, NE>::load(x + (r + u * step) * C + chunk * NE, v[u]);
-#pragma unroll
-            for (int u = 0; u < BN_UNROLL; ++u)
-#pragma unroll
-                for (int i = 0; i < NE; ++i) {
-                    const float d = v[u][i] - piv[i];
-                    acc[0][i] += d;
-                    acc[1][i] += d * d;
-                }
-        }
-        for (; r < P; r += step) {
-            float v[NE];
-            BnIO<T, NE>::load(x + r * C + chunk * NE, v);
-#pragma unroll
-            for (int i = 0; i < NE; ++i) {
-                const float d = v[i] - piv[i];
-                acc[0][i] += d;
-                acc[1][i] += d * d;
-            }
-        }
-    }
-    block_column_reduce<2, NE>(acc, cpr, rpi, C, part);
 }
 
 // Sum the per-workgroup partials of two quantities: a workgroup owns FIN_CH channels, each
@@ -183,17 +232,57 @@ __device__ __forceinline__ bool finalize_sums(const float *__restrict__ part, in
     return true;
 }
 
-// partials -> mean, rstd (+ running-stat update as nn.BatchNorm does); grid = ceil(C/FIN_CH)
+// ------------------------------------------------------------------ forward statistics
+// partials -> mean, rstd (+ running statistics and the batch counter, as nn.BatchNorm does)
+template <typename T>
+__global__ __launch_bounds__(BN_THREADS) void rowbn_stats_kernel(const T *__restrict__ x, long long P, int C,
+                                                                 float *__restrict__ ws) {
+    constexpr int NE = BnElems<T>::NE;
+    const int cpr = C / NE, rpi = BN_THREADS / cpr;  // chunks per row, rows per iteration
+    const int tid = threadIdx.x;
+    const int chunk = tid % cpr, rsub = tid / cpr;
+    float *part = ws + WS_HEAD;
+    float acc[2][NE];
+#pragma unroll
+    for (int i = 0; i < NE; ++i) { acc[0][i] = 0.0f; acc[1][i] = 0.0f; }
+    if (rsub < rpi) {
+        float piv[NE];
+        {
+            Chunk<T, NE> p0;
+            p0.load(x + chunk * NE);  // pivot = first row
+            p0.unpack(piv);
+        }
+        struct Stage { Chunk<T, NE> v[TPG_BN_STATS_U]; };
+        const T *xc = x + chunk * NE;
+        pipelined_rows<TPG_BN_STATS_U, Stage>(
+            (long long)blockIdx.x * rpi + rsub, (long long)gridDim.x * rpi, P,
+            [&](Stage &s, int u, long long r) { s.v[u].load(xc + r * C); },
+            [&](const Stage &s, int u, long long) {
+                float v[NE];
+                s.v[u].unpack(v);
+#pragma unroll
+                for (int i = 0; i < NE; ++i) {
+                    const float d = v[i] - piv[i];
+                    acc[0][i] += d;
+                    acc[1][i] += d * d;
+                }
+            });
+    }
+    block_column_reduce<2, NE>(acc, cpr, rpi, C, part);
+}
+
+// partials -> mean, rstd (+ running statistics and the batch counter, as nn.BatchNorm does);
+// grid = ceil(C/FIN_CH)
 template <typename T>
 __global__ __launch_bounds__(BN_THREADS) void rowbn_stats_finalize_kernel(
-    const T *__restrict__ x, const float *__restrict__ part, int G, long long P, int C, float eps,
+    const T *__restrict__ x, const float *__restrict__ ws, int G, long long P, int C, float eps,
     float momentum, float *__restrict__ running_mean, float *__restrict__ running_var,
     long long *__restrict__ num_batches_tracked, float *__restrict__ mean, float *__restrict__ rstd) {
     int c;
     double s, ss;
     if (num_batches_tracked && blockIdx.x == 0 && threadIdx.x == 0) *num_batches_tracked += 1;
-    if (!finalize_sums(part, G, C, c, s, ss)) return;
-    const double piv = BnIO<T, BnElems<T>::NE>::one(x + c);
+    if (!finalize_sums(ws + WS_HEAD, G, C, c, s, ss)) return;
+    const double piv = Chunk<T, BnElems<T>::NE>::one(x + c);
     const double m = s / (double)P;
     double var = ss / (double)P - m * m;  // biased, about the pivot
     var = var < 0.0 ? 0.0 : var;
@@ -217,36 +306,34 @@ __global__ __launch_bounds__(BN_THREADS) void rowbn_apply_kernel(
     const int chunk = threadIdx.x % cpr, rsub = threadIdx.x / cpr, col = chunk * NE;
     if (rsub >= rpi) return;
     float a[NE], b[NE], mu[NE];
+    ld_consts<NE>(mean, col, 0.0f, mu);
+    ld_consts<NE>(rstd, col, 1.0f, a);
+    ld_consts<NE>(beta, col, 0.0f, b);
+    {
+        float gm[NE];
+        ld_consts<NE>(gamma, col, 1.0f, gm);
 #pragma unroll
-    for (int i = 0; i < NE; ++i) {
-        mu[i] = ld_mean(mean, col + i);
-        a[i] = (gamma ? gamma[col + i] : 1.0f) * ld_rstd(rstd, col + i);
-        b[i] = beta ? beta[col + i] : 0.0f;
+        for (int i = 0; i < NE; ++i) a[i] = gm[i] * a[i];
     }
-    const long long step = (long long)gridDim.x * rpi;
-    long long r = (long long)blockIdx.x * rpi + rsub;
-    for (; r + (BN_UNROLL - 1) * step < P; r += BN_UNROLL * step) {
-        float v[BN_UNROLL][NE];
+    struct Stage { Chunk<TI, NE> v[BN_UNROLL]; };
+    const TI *xc = x + col;
+    TO *yc = y + col;
+    pipelined_rows<BN_UNROLL, Stage>(
+        (long long)blockIdx.x * rpi + rsub, (long long)gridDim.x * rpi, P,
+        [&](Stage &s, int u, long long r) { s.v[u].load(xc + r * C); },
+        [&](const Stage &s, int u, long long r) {
+            float v[NE];
+            s.v[u].unpack(v);
 #pragma unroll
-        for (int u = 0; u < BN_UNROLL; ++u) BnIO<TI, NE>::load(x + (r + u * step) * C + col, v[u]);
-#pragma unroll
-        for (int u = 0; u < BN_UNROLL; ++u) {
-#pragma unroll
-            for (int i = 0; i < NE; ++i) v[u][i] = lrelu_f(bn_z(v[u][i], mu[i], a[i], b[i]), slope);
-            BnIO<TO, NE>::store(y + (r + u * step) * C + col, v[u]);
-        }
-    }
-    for (; r < P; r += step) {
-        float v[NE];
-        BnIO<TI, NE>::load(x + r * C + col, v);
-#pragma unroll
-        for (int i = 0; i < NE; ++i) v[i] = lrelu_f(bn_z(v[i], mu[i], a[i], b[i]), slope);
-        BnIO<TO, NE>::store(y + r * C + col, v);
-    }
+            for (int i = 0; i < NE; ++i) v[i] = lrelu_f(bn_z(v[i], mu[i], a[i], b[i]), slope);
+            Chunk<TO, NE>::store(yc + r * C, v);
+        });
 }
 
-// groups of K consecutive rows -> one row (max) + arg-max byte per channel (first maximum)
-template <typename TI, typename TO>
+// groups of K consecutive rows -> one row (max) + arg-max byte per channel (first maximum).
+// A thread walks whole groups; the walk over (group, k) is one pipeline (U rows per stage,
+// U | K), so the loads of the next group's first rows are in flight while a group is closed.
+template <typename TI, typename TO, int U>
 __global__ __launch_bounds__(BN_THREADS) void rowbn_apply_max_kernel(
     const TI *__restrict__ x, long long Gp, int K, int C, const float *__restrict__ mean,
     const float *__restrict__ rstd, const float *__restrict__ gamma, const float *__restrict__ beta,
@@ -256,145 +343,170 @@ __global__ __launch_bounds__(BN_THREADS) void rowbn_apply_max_kernel(
     const int chunk = threadIdx.x % cpr, rsub = threadIdx.x / cpr, col = chunk * NE;
     if (rsub >= rpi) return;
     float a[NE], b[NE], mu[NE];
+    ld_consts<NE>(mean, col, 0.0f, mu);
+    ld_consts<NE>(rstd, col, 1.0f, a);
+    ld_consts<NE>(beta, col, 0.0f, b);
+    {
+        float gm[NE];
+        ld_consts<NE>(gamma, col, 1.0f, gm);
 #pragma unroll
-    for (int i = 0; i < NE; ++i) {
-        mu[i] = ld_mean(mean, col + i);
-        a[i] = (gamma ? gamma[col + i] : 1.0f) * ld_rstd(rstd, col + i);
-        b[i] = beta ? beta[col + i] : 0.0f;
+        for (int i = 0; i < NE; ++i) a[i] = gm[i] * a[i];
     }
-    for (long long grp = (long long)blockIdx.x * rpi + rsub; grp < Gp; grp += (long long)gridDim.x * rpi) {
-        float best[NE];
-        int bk[NE];
+    const long long gstep = (long long)gridDim.x * rpi;
+    long long grp = (long long)blockIdx.x * rpi + rsub;
+    int k = 0;
+    bool have = grp < Gp;
+    Chunk<TI, NE> cur[U], nxt[U];
+    const TI *xc = x + col;
+    if (have) {
 #pragma unroll
-        for (int i = 0; i < NE; ++i) { best[i] = -INFINITY; bk[i] = 0; }
-        const TI *xg = x + grp * K * C + col;
-        int k = 0;
-        for (; k + BN_UNROLL <= K; k += BN_UNROLL) {
-            float v[BN_UNROLL][NE];
+        for (int u = 0; u < U; ++u) cur[u].load(xc + (grp * K + u) * C);
+    }
+    float best[NE];
+    int bk[NE];
 #pragma unroll
-            for (int u = 0; u < BN_UNROLL; ++u) BnIO<TI, NE>::load(xg + (size_t)(k + u) * C, v[u]);
+    for (int i = 0; i < NE; ++i) { best[i] = -INFINITY; bk[i] = 0; }
+    while (have) {
+        int kn = k + U;
+        long long grpn = grp;
+        if (kn >= K) { kn = 0; grpn = grp + gstep; }
+        const bool have_n = grpn < Gp;
+        if (have_n) {
 #pragma unroll
-            for (int u = 0; u < BN_UNROLL; ++u)
-#pragma unroll
-                for (int i = 0; i < NE; ++i) {
-                    const float z = lrelu_f(bn_z(v[u][i], mu[i], a[i], b[i]), slope);
-                    if (z > best[i]) { best[i] = z; bk[i] = k + u; }
-                }
+            for (int u = 0; u < U; ++u) nxt[u].load(xc + (grpn * K + kn + u) * C);
         }
-        for (; k < K; ++k) {
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
             float v[NE];
-            BnIO<TI, NE>::load(xg + (size_t)k * C, v);
+            cur[u].unpack(v);
 #pragma unroll
             for (int i = 0; i < NE; ++i) {
                 const float z = lrelu_f(bn_z(v[i], mu[i], a[i], b[i]), slope);
-                if (z > best[i]) { best[i] = z; bk[i] = k; }
+                if (z > best[i]) { best[i] = z; bk[i] = k + u; }
             }
         }
-        BnIO<TO, NE>::store(y + grp * C + col, best);
-        // NE arg-max bytes (8-byte aligned for NE = 8, 4-byte for NE = 4)
-        if constexpr (NE == 8) {
-            const unsigned lo = bk[0] | (bk[1] << 8) | (bk[2] << 16) | ((unsigned)bk[3] << 24);
-            const unsigned hi = bk[4] | (bk[5] << 8) | (bk[6] << 16) | ((unsigned)bk[7] << 24);
-            *reinterpret_cast<uint2 *>(arg + grp * C + col) = make_uint2(lo, hi);
-        } else {
-            *reinterpret_cast<unsigned *>(arg + grp * C + col) =
-                bk[0] | (bk[1] << 8) | (bk[2] << 16) | ((unsigned)bk[3] << 24);
+        if (kn == 0) {   // group complete
+            Chunk<TO, NE>::store(y + grp * C + col, best);
+            // NE arg-max bytes (8-byte aligned for NE = 8, 4-byte for NE = 4)
+            if constexpr (NE == 8) {
+                const unsigned lo = bk[0] | (bk[1] << 8) | (bk[2] << 16) | ((unsigned)bk[3] << 24);
+                const unsigned hi = bk[4] | (bk[5] << 8) | (bk[6] << 16) | ((unsigned)bk[7] << 24);
+                *reinterpret_cast<uint2 *>(arg + grp * C + col) = make_uint2(lo, hi);
+            } else {
+                *reinterpret_cast<unsigned *>(arg + grp * C + col) =
+                    bk[0] | (bk[1] << 8) | (bk[2] << 16) | ((unsigned)bk[3] << 24);
+            }
+#pragma unroll
+            for (int i = 0; i < NE; ++i) { best[i] = -INFINITY; bk[i] = 0; }
         }
+#pragma unroll
+        for (int u = 0; u < U; ++u) cur[u] = nxt[u];
+        k = kn;
+        grp = grpn;
+        have = have_n;
     }
 }
 
 // ------------------------------------------------------------------ backward reductions
-// part[(block*2+0)*C + c] = sum g, part[(block*2+1)*C + c] = sum g*xhat
+// partials (sum g, sum g*xhat) -> dgamma, dbeta (fp32) and the two per-channel constants of dx
+// (c12 = {sum g / P, sum g*xhat / P}, zero for eval-mode statistics); grid = ceil(C/FIN_CH)
+__global__ __launch_bounds__(BN_THREADS) void rowbn_bwd_finalize_kernel(const float *__restrict__ ws, int G,
+                                                                        long long P, int C, int training,
+                                                                        float *__restrict__ dgamma,
+                                                                        float *__restrict__ dbeta,
+                                                                        float *__restrict__ c12) {
+    int c;
+    double s, sx;
+    if (!finalize_sums(ws + WS_HEAD, G, C, c, s, sx)) return;
+    if (dbeta) dbeta[c] = (float)s;
+    if (dgamma) dgamma[c] = (float)sx;
+    c12[c] = training ? (float)(s / (double)P) : 0.0f;       // eval-mode BN: no batch terms
+    c12[C + c] = training ? (float)(sx / (double)P) : 0.0f;
+}
+
 template <typename TI, typename TG>
 __global__ __launch_bounds__(BN_THREADS) void rowbn_bwd_reduce_kernel(
     const TG *__restrict__ gy, const TI *__restrict__ x, long long P, int C, const float *__restrict__ mean,
     const float *__restrict__ rstd, const float *__restrict__ gamma, const float *__restrict__ beta,
-    float slope, float *__restrict__ part) {
+    float slope, float *__restrict__ ws) {
     constexpr int NE = (sizeof(TI) == 2 || sizeof(TG) == 2) ? 8 : 4;
     const int cpr = C / NE, rpi = BN_THREADS / cpr;
     const int tid = threadIdx.x;
-    const int chunk = tid % cpr, rsub = tid / cpr;
-    float acc[2][NE], a[NE], b[NE], mu[NE], rs[NE];
+    const int chunk = tid % cpr, rsub = tid / cpr, col = chunk * NE;
+    float acc[2][NE];
 #pragma unroll
-    for (int i = 0; i < NE; ++i) {
-        acc[0][i] = 0.0f; acc[1][i] = 0.0f;
-        const int c = chunk * NE + i;
-        mu[i] = ld_mean(mean, c); rs[i] = ld_rstd(rstd, c);
-        a[i] = (gamma ? gamma[c] : 1.0f) * rs[i];
-        b[i] = beta ? beta[c] : 0.0f;
-    }
+    for (int i = 0; i < NE; ++i) { acc[0][i] = 0.0f; acc[1][i] = 0.0f; }
     if (rsub < rpi) {
-        const long long step = (long long)gridDim.x * rpi;
-        long long r = (long long)blockIdx.x * rpi + rsub;
-        constexpr int U = 2;
-        for (; r + (U - 1) * step < P; r += U * step) {
-            float v[U][NE], g[U][NE];
+        float a[NE], b[NE], mu[NE], rs[NE];
+        ld_consts<NE>(mean, col, 0.0f, mu);
+        ld_consts<NE>(rstd, col, 1.0f, rs);
+        ld_consts<NE>(beta, col, 0.0f, b);
+        ld_consts<NE>(gamma, col, 1.0f, a);
 #pragma unroll
-            for (int u = 0; u < U; ++u) {
-                BnIO<TI, NE>::load(x + (r + u * step) * C + chunk * NE, v[u]);
-                BnIO<TG, NE>::load(gy + (r + u * step) * C + chunk * NE, g[u]);
-            }
-#pragma unroll
-            for (int u = 0; u < U; ++u)
+        for (int i = 0; i < NE; ++i) a[i] = a[i] * rs[i];
+        struct Stage { Chunk<TI, NE> v[BN_BWD_U]; Chunk<TG, NE> g[BN_BWD_U]; };
+        const TI *xc = x + col;
+        const TG *gc = gy + col;
+        pipelined_rows<BN_BWD_U, Stage>(
+            (long long)blockIdx.x * rpi + rsub, (long long)gridDim.x * rpi, P,
+            [&](Stage &s, int u, long long r) { s.v[u].load(xc + r * C); s.g[u].load(gc + r * C); },
+            [&](const Stage &s, int u, long long) {
+                float v[NE], g[NE];
+                s.v[u].unpack(v);
+                s.g[u].unpack(g);
 #pragma unroll
                 for (int i = 0; i < NE; ++i) {
-                    const float gg = bn_z(v[u][i], mu[i], a[i], b[i]) > 0.0f ? g[u][i] : g[u][i] * slope;
+                    const float gg = bn_z(v[i], mu[i], a[i], b[i]) > 0.0f ? g[i] : g[i] * slope;
                     acc[0][i] += gg;
-                    acc[1][i] += gg * ((v[u][i] - mu[i]) * rs[i]);
+                    acc[1][i] += gg * ((v[i] - mu[i]) * rs[i]);
                 }
-        }
-        for (; r < P; r += step) {
-            float v[NE], g[NE];
-            BnIO<TI, NE>::load(x + r * C + chunk * NE, v);
-            BnIO<TG, NE>::load(gy + r * C + chunk * NE, g);
-#pragma unroll
-            for (int i = 0; i < NE; ++i) {
-                const float gg = bn_z(v[i], mu[i], a[i], b[i]) > 0.0f ? g[i] : g[i] * slope;
-                acc[0][i] += gg;
-                acc[1][i] += gg * ((v[i] - mu[i]) * rs[i]);
-            }
-        }
+            });
     }
-    block_column_reduce<2, NE>(acc, cpr, rpi, C, part);
+    block_column_reduce<2, NE>(acc, cpr, rpi, C, ws + WS_HEAD);
 }
 
 // max variant: gy is (P/K, C); only the arg-max row of each group carries gradient.
 // With the forward's output y (stored like gy) the arg-max row's pre-activation is
 // z = y > 0 ? y : y / slope and xhat = (z - beta) / gamma: two small streaming reads instead of
 // one scattered 2/4-byte load of x per (group, channel).  Per-channel guard: the inversion is
-// used only where it is well conditioned.
+// used only where it is well conditioned (|beta| <= 4|gamma|); y == nullptr: always gather.
 template <typename TI, typename TG>
-__global__ __launch_bounds__(BN_THREADS) void rowbn_bwd_reduce_max_y_kernel(
+__global__ __launch_bounds__(BN_THREADS) void rowbn_bwd_reduce_max_kernel(
     const TG *__restrict__ gy, const TG *__restrict__ y, const TI *__restrict__ x,
     const uint8_t *__restrict__ arg, long long Gp, int K, int C, const float *__restrict__ mean,
     const float *__restrict__ rstd, const float *__restrict__ gamma, const float *__restrict__ beta,
-    float slope, float *__restrict__ part) {
+    float slope, float *__restrict__ ws) {
     constexpr int NE = (sizeof(TI) == 2 || sizeof(TG) == 2) ? 8 : 4;
     const int cpr = C / NE, rpi = BN_THREADS / cpr;
     const int tid = threadIdx.x;
-    const int chunk = tid % cpr, rsub = tid / cpr;
-    float acc[2][NE], a[NE], b[NE], mu[NE], rs[NE], ig[NE];
-    bool inv[NE];
-    const float islope = slope != 0.0f ? 1.0f / slope : 0.0f;
+    const int chunk = tid % cpr, rsub = tid / cpr, col = chunk * NE;
+    float acc[2][NE];
 #pragma unroll
-    for (int i = 0; i < NE; ++i) {
-        acc[0][i] = 0.0f; acc[1][i] = 0.0f;
-        const int c = chunk * NE + i;
-        mu[i] = ld_mean(mean, c); rs[i] = ld_rstd(rstd, c);
-        const float gm = gamma ? gamma[c] : 1.0f;
-        a[i] = gm * rs[i];
-        b[i] = beta ? beta[c] : 0.0f;
-        inv[i] = fabsf(b[i]) <= 4.0f * fabsf(gm);
-        ig[i] = inv[i] ? 1.0f / gm : 0.0f;
-    }
+    for (int i = 0; i < NE; ++i) { acc[0][i] = 0.0f; acc[1][i] = 0.0f; }
     if (rsub < rpi) {
+        float a[NE], b[NE], mu[NE], rs[NE], ig[NE];
+        bool inv[NE];
+        const float islope = slope != 0.0f ? 1.0f / slope : 0.0f;
+        ld_consts<NE>(mean, col, 0.0f, mu);
+        ld_consts<NE>(rstd, col, 1.0f, rs);
+        ld_consts<NE>(beta, col, 0.0f, b);
+        ld_consts<NE>(gamma, col, 1.0f, a);
+#pragma unroll
+        for (int i = 0; i < NE; ++i) {
+            inv[i] = y != nullptr && fabsf(b[i]) <= 4.0f * fabsf(a[i]);
+            ig[i] = inv[i] ? 1.0f / a[i] : 0.0f;
+            a[i] = a[i] * rs[i];
+        }
         for (long long r = (long long)blockIdx.x * rpi + rsub; r < Gp; r += (long long)gridDim.x * rpi) {
             float g[NE], yy[NE];
-            BnIO<TG, NE>::load(gy + r * C + chunk * NE, g);
-            BnIO<TG, NE>::load(y + r * C + chunk * NE, yy);
+            Chunk<TG, NE> cg, cy;
+            cg.load(gy + r * C + col);
+            if (y != nullptr) cy.load(y + r * C + col);
+            else cy = cg;
+            cg.unpack(g);
+            cy.unpack(yy);
 #pragma unroll
             for (int i = 0; i < NE; ++i) {
-                const int c = chunk * NE + i;
                 if (inv[i]) {
                     const bool pos = yy[i] > 0.0f;
                     const float gg = pos ? g[i] : g[i] * slope;
@@ -402,8 +514,9 @@ __global__ __launch_bounds__(BN_THREADS) void rowbn_bwd_reduce_max_y_kernel(
                     acc[0][i] += gg;
                     acc[1][i] += gg * ((z - b[i]) * ig[i]);
                 } else {
+                    const int c = col + i;
                     const int k = arg[r * C + c];
-                    const float v = BnIO<TI, NE>::one(x + (r * K + k) * C + c);
+                    const float v = Chunk<TI, NE>::one(x + (r * K + k) * C + c);
                     const float gg = bn_z(v, mu[i], a[i], b[i]) > 0.0f ? g[i] : g[i] * slope;
                     acc[0][i] += gg;
                     acc[1][i] += gg * ((v - mu[i]) * rs[i]);
@@ -411,64 +524,53 @@ __global__ __launch_bounds__(BN_THREADS) void rowbn_bwd_reduce_max_y_kernel(
             }
         }
     }
-    block_column_reduce<2, NE>(acc, cpr, rpi, C, part);
+    block_column_reduce<2, NE>(acc, cpr, rpi, C, ws + WS_HEAD);
 }
 
-template <typename TI, typename TG>
-__global__ __launch_bounds__(BN_THREADS) void rowbn_bwd_reduce_max_kernel(
-    const TG *__restrict__ gy, const TI *__restrict__ x, const uint8_t *__restrict__ arg, long long Gp,
-    int K, int C, const float *__restrict__ mean, const float *__restrict__ rstd,
-    const float *__restrict__ gamma, const float *__restrict__ beta, float slope, float *__restrict__ part) {
-    constexpr int NE = (sizeof(TI) == 2 || sizeof(TG) == 2) ? 8 : 4;
-    const int cpr = C / NE, rpi = BN_THREADS / cpr;
-    const int tid = threadIdx.x;
-    const int chunk = tid % cpr, rsub = tid / cpr;
-    float acc[2][NE], a[NE], b[NE], mu[NE], rs[NE];
-#pragma unroll
-    for (int i = 0; i < NE; ++i) {
-        acc[0][i] = 0.0f; acc[1][i] = 0.0f;
-        const int c = chunk * NE + i;
-        mu[i] = ld_mean(mean, c); rs[i] = ld_rstd(rstd, c);
-        a[i] = (gamma ? gamma[c] : 1.0f) * rs[i];
-        b[i] = beta ? beta[c] : 0.0f;
-    }
-    if (rsub < rpi) {
-        for (long long r = (long long)blockIdx.x * rpi + rsub; r < Gp; r += (long long)gridDim.x * rpi) {
-            float g[NE];
-            BnIO<TG, NE>::load(gy + r * C + chunk * NE, g);
-#pragma unroll
-            for (int i = 0; i < NE; ++i) {
-                const int c = chunk * NE + i;
-                const int k = arg[r * C + c];
-                const float v = BnIO<TI, NE>::one(x + (r * K + k) * C + c);
-                const float gg = bn_z(v, mu[i], a[i], b[i]) > 0.0f ? g[i] : g[i] * slope;
-                acc[0][i] += gg;
-                acc[1][i] += gg * ((v - mu[i]) * rs[i]);
-            }
-        }
-    }
-    block_column_reduce<2, NE>(acc, cpr, rpi, C, part);
-}
-
-// partials -> dgamma, dbeta (fp32) and the two per-channel constants of dx; grid = ceil(C/FIN_CH)
-__global__ __launch_bounds__(BN_THREADS) void rowbn_bwd_finalize_kernel(const float *__restrict__ part, int G,
-                                                                        long long P, int C, int training,
-                                                                        float *__restrict__ dgamma,
-                                                                        float *__restrict__ dbeta,
-                                                                        float *__restrict__ c12) {
-    int c;
-    double s, sx;
-    if (!finalize_sums(part, G, C, c, s, sx)) return;
-    if (dbeta) dbeta[c] = (float)s;
-    if (dgamma) dgamma[c] = (float)sx;
-    c12[c] = training ? (float)(s / (double)P) : 0.0f;       // eval-mode BN: no batch terms
-    c12[C + c] = training ? (float)(sx / (double)P) : 0.0f;
-}
-
-// dx = a * (g - c1 - xhat*c2); K > 0: g lives only on each group's arg-max row
+// dx = a * (g - c1 - xhat*c2), K == 0
 template <typename TI, typename TG>
 __global__ __launch_bounds__(BN_THREADS) void rowbn_bwd_apply_kernel(
-    const TG *__restrict__ gy, const TI *__restrict__ x, const uint8_t *__restrict__ arg, long long P, int K,
+    const TG *__restrict__ gy, const TI *__restrict__ x, long long P, int C, const float *__restrict__ mean,
+    const float *__restrict__ rstd, const float *__restrict__ gamma, const float *__restrict__ beta,
+    float slope, const float *__restrict__ c12, TI *__restrict__ dx) {
+    constexpr int NE = (sizeof(TI) == 2 || sizeof(TG) == 2) ? 8 : 4;
+    const int cpr = C / NE, rpi = BN_THREADS / cpr;
+    const int chunk = threadIdx.x % cpr, rsub = threadIdx.x / cpr, col = chunk * NE;
+    if (rsub >= rpi) return;
+    float a[NE], b[NE], mu[NE], rs[NE], c1[NE], c2[NE];
+    ld_consts<NE>(mean, col, 0.0f, mu);
+    ld_consts<NE>(rstd, col, 1.0f, rs);
+    ld_consts<NE>(beta, col, 0.0f, b);
+    ld_consts<NE>(gamma, col, 1.0f, a);
+    ld_consts<NE>(c12, col, 0.0f, c1);
+    ld_consts<NE>(c12 ? c12 + C : nullptr, col, 0.0f, c2);
+#pragma unroll
+    for (int i = 0; i < NE; ++i) a[i] = a[i] * rs[i];
+    struct Stage { Chunk<TI, NE> v[BN_BWD_U]; Chunk<TG, NE> g[BN_BWD_U]; };
+    const TI *xc = x + col;
+    const TG *gc = gy + col;
+    TI *dc = dx + col;
+    pipelined_rows<BN_BWD_U, Stage>(
+        (long long)blockIdx.x * rpi + rsub, (long long)gridDim.x * rpi, P,
+        [&](Stage &s, int u, long long r) { s.v[u].load(xc + r * C); s.g[u].load(gc + r * C); },
+        [&](const Stage &s, int u, long long r) {
+            float v[NE], g[NE];
+            s.v[u].unpack(v);
+            s.g[u].unpack(g);
+#pragma unroll
+            for (int i = 0; i < NE; ++i) {
+                const float gg = bn_z(v[i], mu[i], a[i], b[i]) > 0.0f ? g[i] : g[i] * slope;
+                v[i] = a[i] * (gg - c1[i] - (v[i] - mu[i]) * rs[i] * c2[i]);
+            }
+            Chunk<TI, NE>::store(dc + r * C, v);
+        });
+}
+
+// K > 0: g lives only on each group's arg-max row; a thread walks whole groups so that gy and
+// the arg-max bytes are read once per group; (group, k) walked as one pipeline like the forward
+template <typename TI, typename TG, int U>
+__global__ __launch_bounds__(BN_THREADS) void rowbn_bwd_apply_max_kernel(
+    const TG *__restrict__ gy, const TI *__restrict__ x, const uint8_t *__restrict__ arg, long long Gp, int K,
     int C, const float *__restrict__ mean, const float *__restrict__ rstd, const float *__restrict__ gamma,
     const float *__restrict__ beta, float slope, const float *__restrict__ c12, TI *__restrict__ dx) {
     constexpr int NE = (sizeof(TI) == 2 || sizeof(TG) == 2) ? 8 : 4;
@@ -476,84 +578,69 @@ __global__ __launch_bounds__(BN_THREADS) void rowbn_bwd_apply_kernel(
     const int chunk = threadIdx.x % cpr, rsub = threadIdx.x / cpr, col = chunk * NE;
     if (rsub >= rpi) return;
     float a[NE], b[NE], mu[NE], rs[NE], c1[NE], c2[NE];
+    ld_consts<NE>(mean, col, 0.0f, mu);
+    ld_consts<NE>(rstd, col, 1.0f, rs);
+    ld_consts<NE>(beta, col, 0.0f, b);
+    ld_consts<NE>(gamma, col, 1.0f, a);
+    ld_consts<NE>(c12, col, 0.0f, c1);
+    ld_consts<NE>(c12 ? c12 + C : nullptr, col, 0.0f, c2);
 #pragma unroll
-    for (int i = 0; i < NE; ++i) {
-        mu[i] = ld_mean(mean, col + i);
-        rs[i] = ld_rstd(rstd, col + i);
-        a[i] = (gamma ? gamma[col + i] : 1.0f) * rs[i];
-        b[i] = beta ? beta[col + i] : 0.0f;
-        c1[i] = c12[col + i];
-        c2[i] = c12[C + col + i];
-    }
-    const long long step = (long long)gridDim.x * rpi;
-    if (K == 0) {
-        constexpr int U = 2;
-        long long r = (long long)blockIdx.x * rpi + rsub;
-        for (; r + (U - 1) * step < P; r += U * step) {
-            float v[U][NE], g[U][NE];
-#pragma unroll
-            for (int u = 0; u < U; ++u) {
-                BnIO<TI, NE>::load(x + (r + u * step) * C + col, v[u]);
-                BnIO<TG, NE>::load(gy + (r + u * step) * C + col, g[u]);
-            }
-#pragma unroll
-            for (int u = 0; u < U; ++u) {
-#pragma unroll
-                for (int i = 0; i < NE; ++i) {
-                    const float gg = bn_z(v[u][i], mu[i], a[i], b[i]) > 0.0f ? g[u][i] : g[u][i] * slope;
-                    v[u][i] = a[i] * (gg - c1[i] - (v[u][i] - mu[i]) * rs[i] * c2[i]);
-                }
-                BnIO<TI, NE>::store(dx + (r + u * step) * C + col, v[u]);
-            }
+    for (int i = 0; i < NE; ++i) a[i] = a[i] * rs[i];
+    const long long gstep = (long long)gridDim.x * rpi;
+    long long grp = (long long)blockIdx.x * rpi + rsub;
+    int k = 0;
+    bool have = grp < Gp;
+    Chunk<TI, NE> cur[U], nxt[U];
+    Chunk<TG, NE> cgy, ngy;
+    unsigned ak_lo = 0, ak_hi = 0, nk_lo = 0, nk_hi = 0;     // NE arg-max bytes
+    const TI *xc = x + col;
+    auto load_group = [&](long long g_, Chunk<TG, NE> &cg, unsigned &lo, unsigned &hi) {
+        cg.load(gy + g_ * C + col);
+        if constexpr (NE == 8) {
+            const uint2 t = *reinterpret_cast<const uint2 *>(arg + g_ * C + col);
+            lo = t.x; hi = t.y;
+        } else {
+            lo = *reinterpret_cast<const unsigned *>(arg + g_ * C + col);
+            hi = 0;
         }
-        for (; r < P; r += step) {
-            float v[NE], g[NE];
-            BnIO<TI, NE>::load(x + r * C + col, v);
-            BnIO<TG, NE>::load(gy + r * C + col, g);
+    };
+    if (have) {
+        load_group(grp, cgy, ak_lo, ak_hi);
+        ngy = cgy;
 #pragma unroll
-            for (int i = 0; i < NE; ++i) {
-                const float gg = bn_z(v[i], mu[i], a[i], b[i]) > 0.0f ? g[i] : g[i] * slope;
-                v[i] = a[i] * (gg - c1[i] - (v[i] - mu[i]) * rs[i] * c2[i]);
-            }
-            BnIO<TI, NE>::store(dx + r * C + col, v);
-        }
-        return;
+        for (int u = 0; u < U; ++u) cur[u].load(xc + (grp * K + u) * C);
     }
-    // K > 0: walk whole groups so that gy / arg-max are read once per group
-    const long long Gp = P / K;
-    for (long long grp = (long long)blockIdx.x * rpi + rsub; grp < Gp; grp += step) {
+    while (have) {
+        int kn = k + U;
+        long long grpn = grp;
+        if (kn >= K) { kn = 0; grpn = grp + gstep; }
+        const bool have_n = grpn < Gp;
+        if (have_n) {
+            if (kn == 0) load_group(grpn, ngy, nk_lo, nk_hi);
+#pragma unroll
+            for (int u = 0; u < U; ++u) nxt[u].load(xc + (grpn * K + kn + u) * C);
+        }
         float g[NE];
-        int ak[NE];
-        BnIO<TG, NE>::load(gy + grp * C + col, g);
+        cgy.unpack(g);
 #pragma unroll
-        for (int i = 0; i < NE; ++i) ak[i] = arg[grp * C + col + i];
-        int k = 0;
-        for (; k + BN_UNROLL <= K; k += BN_UNROLL) {
-            float v[BN_UNROLL][NE];
-#pragma unroll
-            for (int u = 0; u < BN_UNROLL; ++u) BnIO<TI, NE>::load(x + (grp * K + k + u) * C + col, v[u]);
-#pragma unroll
-            for (int u = 0; u < BN_UNROLL; ++u) {
-#pragma unroll
-                for (int i = 0; i < NE; ++i) {
-                    float gg = 0.0f;
-                    if (ak[i] == k + u) gg = bn_z(v[u][i], mu[i], a[i], b[i]) > 0.0f ? g[i] : g[i] * slope;
-                    v[u][i] = a[i] * (gg - c1[i] - (v[u][i] - mu[i]) * rs[i] * c2[i]);
-                }
-                BnIO<TI, NE>::store(dx + (grp * K + k + u) * C + col, v[u]);
-            }
-        }
-        for (; k < K; ++k) {
+        for (int u = 0; u < U; ++u) {
             float v[NE];
-            BnIO<TI, NE>::load(x + (grp * K + k) * C + col, v);
+            cur[u].unpack(v);
 #pragma unroll
             for (int i = 0; i < NE; ++i) {
+                const int ak = (int)(((i < 4 ? ak_lo : ak_hi) >> (8 * (i & 3))) & 0xffu);
                 float gg = 0.0f;
-                if (ak[i] == k) gg = bn_z(v[i], mu[i], a[i], b[i]) > 0.0f ? g[i] : g[i] * slope;
+                if (ak == k + u) gg = bn_z(v[i], mu[i], a[i], b[i]) > 0.0f ? g[i] : g[i] * slope;
                 v[i] = a[i] * (gg - c1[i] - (v[i] - mu[i]) * rs[i] * c2[i]);
             }
-            BnIO<TI, NE>::store(dx + (grp * K + k) * C + col, v);
+            Chunk<TI, NE>::store(dx + (grp * K + k + u) * C + col, v);
         }
+        if (kn == 0) { cgy = ngy; ak_lo = nk_lo; ak_hi = nk_hi; }
+#pragma unroll
+        for (int u = 0; u < U; ++u) cur[u] = nxt[u];
+        k = kn;
+        grp = grpn;
+        have = have_n;
     }
 }
 
@@ -562,17 +649,18 @@ int row_blocks(long long rows, int rpi, int per_thread, int cap) {
     long long b = (rows + (long long)rpi * per_thread - 1) / ((long long)rpi * per_thread);
     return (int)(b < 1 ? 1 : (b > cap ? cap : b));
 }
-int stats_blocks(long long rows, int rpi) { return row_blocks(rows, rpi, 2 * BN_UNROLL, BN_MAX_BLOCKS); }
+int stats_blocks(long long rows, int rpi) { return row_blocks(rows, rpi, TPG_BN_STATS_ROWS, BN_MAX_BLOCKS); }
 bool bn_shape_ok(int dtype_a, int dtype_b, int C) {
     const int ne = (dtype_a == TPG_DTYPE_BF16 || dtype_b == TPG_DTYPE_BF16) ? 8 : 4;
     return C > 0 && C % ne == 0 && C / 4 <= BN_THREADS;   // <= 1024 channels (column-sum layout)
 }
 bool bn_dtype_ok(int d) { return d == TPG_DTYPE_F32 || d == TPG_DTYPE_BF16; }
+int group_unroll(int K) { return K % 4 == 0 ? 4 : (K % 2 == 0 ? 2 : 1); }
 
 }  // namespace
 
 extern "C" size_t tpg_rowbn_workspace_bytes(int C) {
-    return sizeof(float) * ((size_t)BN_MAX_BLOCKS * 2 * C + 2 * (size_t)C);
+    return sizeof(float) * (WS_HEAD + (size_t)BN_MAX_BLOCKS * 2 * C + 2 * (size_t)C);
 }
 
 extern "C" int tpg_rowbn_fwd(const void *x, int dtype_in, long long P, int K, int C, float eps, float momentum,
@@ -585,24 +673,26 @@ extern "C" int tpg_rowbn_fwd(const void *x, int dtype_in, long long P, int K, in
     if (training ? (!mean || !rstd) : ((mean == nullptr) != (rstd == nullptr))) return TPG_ERR_ARG;
     if (!bn_dtype_ok(dtype_in) || !bn_dtype_ok(dtype_out) || !bn_shape_ok(dtype_in, dtype_out, C))
         return TPG_ERR_UNSUPPORTED;
-    if ((reinterpret_cast<uintptr_t>(x) | reinterpret_cast<uintptr_t>(y)) & 15) return TPG_ERR_UNSUPPORTED;
+    if ((reinterpret_cast<uintptr_t>(x) | reinterpret_cast<uintptr_t>(y) | reinterpret_cast<uintptr_t>(ws)) & 15)
+        return TPG_ERR_UNSUPPORTED;
     hipStream_t st = tpg_stream(stream);
-    float *part = static_cast<float *>(ws);
+    float *wsf = static_cast<float *>(ws);
     if (training && phase != TPG_BN_PHASE_APPLY) {
         // statistics use the INPUT type's vector width
         const int ne = dtype_in == TPG_DTYPE_BF16 ? 8 : 4;
         const int rpi = BN_THREADS / (C / ne);
         const int G = stats_blocks(P, rpi);
+        const dim3 fg((C + FIN_CH - 1) / FIN_CH);
         if (dtype_in == TPG_DTYPE_BF16) {
             const __hip_bfloat16 *xx = static_cast<const __hip_bfloat16 *>(x);
-            hipLaunchKernelGGL(rowbn_stats_kernel<__hip_bfloat16>, dim3(G), dim3(BN_THREADS), 0, st, xx, P, C, part);
-            hipLaunchKernelGGL(rowbn_stats_finalize_kernel<__hip_bfloat16>, dim3((C + FIN_CH - 1) / FIN_CH), dim3(BN_THREADS), 0, st, xx,
-                               part, G, P, C, eps, momentum, running_mean, running_var, num_batches_tracked, mean, rstd);
+            hipLaunchKernelGGL(rowbn_stats_kernel<__hip_bfloat16>, dim3(G), dim3(BN_THREADS), 0, st, xx, P, C, wsf);
+            hipLaunchKernelGGL(rowbn_stats_finalize_kernel<__hip_bfloat16>, fg, dim3(BN_THREADS), 0, st, xx, wsf, G, P,
+                               C, eps, momentum, running_mean, running_var, num_batches_tracked, mean, rstd);
         } else {
             const float *xx = static_cast<const float *>(x);
-            hipLaunchKernelGGL(rowbn_stats_kernel<float>, dim3(G), dim3(BN_THREADS), 0, st, xx, P, C, part);
-            hipLaunchKernelGGL(rowbn_stats_finalize_kernel<float>, dim3((C + FIN_CH - 1) / FIN_CH), dim3(BN_THREADS), 0, st, xx, part, G,
-                               P, C, eps, momentum, running_mean, running_var, num_batches_tracked, mean, rstd);
+            hipLaunchKernelGGL(rowbn_stats_kernel<float>, dim3(G), dim3(BN_THREADS), 0, st, xx, P, C, wsf);
+            hipLaunchKernelGGL(rowbn_stats_finalize_kernel<float>, fg, dim3(BN_THREADS), 0, st, xx, wsf, G, P, C, eps,
+                               momentum, running_mean, running_var, num_batches_tracked, mean, rstd);
         }
     }  // eval mode: the caller has filled mean / rstd from the running statistics
     if (phase == TPG_BN_PHASE_STATS) {
@@ -612,14 +702,20 @@ extern "C" int tpg_rowbn_fwd(const void *x, int dtype_in, long long P, int K, in
     const int ne = (dtype_in == TPG_DTYPE_BF16 || dtype_out == TPG_DTYPE_BF16) ? 8 : 4;
     const int rpi_a = BN_THREADS / (C / ne);
     const long long rows_out = K > 0 ? P / K : P;
-    const dim3 g(K > 0 ? row_blocks(rows_out, rpi_a, 1, 8192) : row_blocks(P, rpi_a, BN_UNROLL, 4096));
+    const dim3 g(K > 0 ? row_blocks(rows_out, rpi_a, 1, TPG_BN_GROUP_CAP)
+                       : row_blocks(P, rpi_a, TPG_BN_APPLY_ROWS, TPG_BN_APPLY_CAP));
     const dim3 blk(BN_THREADS);
+    const int gu = group_unroll(K);
+#define TPG_BN_APPLY_MAX(TI, TO, U)                                                                       \
+    hipLaunchKernelGGL((rowbn_apply_max_kernel<TI, TO, U>), g, blk, 0, st, static_cast<const TI *>(x),    \
+                       rows_out, K, C, mean, rstd, gamma, beta, slope, static_cast<TO *>(y), argmax)
 #define TPG_BN_APPLY(TI, TO)                                                                              \
     do {                                                                                                  \
-        if (K > 0)                                                                                        \
-            hipLaunchKernelGGL((rowbn_apply_max_kernel<TI, TO>), g, blk, 0, st, static_cast<const TI *>(x), \
-                               rows_out, K, C, mean, rstd, gamma, beta, slope, static_cast<TO *>(y), argmax); \
-        else                                                                                              \
+        if (K > 0) {                                                                                      \
+            if (gu == 4) TPG_BN_APPLY_MAX(TI, TO, 4);                                                     \
+            else if (gu == 2) TPG_BN_APPLY_MAX(TI, TO, 2);                                                \
+            else TPG_BN_APPLY_MAX(TI, TO, 1);                                                             \
+        } else                                                                                            \
             hipLaunchKernelGGL((rowbn_apply_kernel<TI, TO>), g, blk, 0, st, static_cast<const TI *>(x), P, C, mean, \
                                rstd, gamma, beta, slope, static_cast<TO *>(y));                           \
     } while (0)
@@ -628,6 +724,7 @@ extern "C" int tpg_rowbn_fwd(const void *x, int dtype_in, long long P, int K, in
     else if (dtype_out == TPG_DTYPE_F32) TPG_BN_APPLY(__hip_bfloat16, float);
     else TPG_BN_APPLY(__hip_bfloat16, __hip_bfloat16);
 #undef TPG_BN_APPLY
+#undef TPG_BN_APPLY_MAX
     TPG_RETURN_IF_LAUNCH_FAILED();
     return TPG_OK;
 }
@@ -640,53 +737,61 @@ extern "C" int tpg_rowbn_bwd(const void *gy, int dtype_g, const void *x, int dty
     if (P <= 0 || C <= 0 || K < 0 || K > 256 || (K > 0 && P % K)) return TPG_ERR_ARG;
     if (!gy || !x || !dx || !ws || (K > 0 && !argmax)) return TPG_ERR_ARG;
     if ((mean == nullptr) != (rstd == nullptr) || (training && !mean)) return TPG_ERR_ARG;
-    // the (gy, y) form of the max-variant sums needs y stored like gy, 16-byte aligned
-    const bool from_y = K > 0 && y && dtype_y == dtype_g && !(reinterpret_cast<uintptr_t>(y) & 15);
     if (!bn_dtype_ok(dtype_in) || !bn_dtype_ok(dtype_g) || !bn_shape_ok(dtype_in, dtype_g, C))
         return TPG_ERR_UNSUPPORTED;
-    if ((reinterpret_cast<uintptr_t>(x) | reinterpret_cast<uintptr_t>(gy) | reinterpret_cast<uintptr_t>(dx)) & 15)
+    if ((reinterpret_cast<uintptr_t>(x) | reinterpret_cast<uintptr_t>(gy) | reinterpret_cast<uintptr_t>(dx) |
+         reinterpret_cast<uintptr_t>(ws)) & 15)
         return TPG_ERR_UNSUPPORTED;
+    // the (gy, y) form of the max-variant sums needs y stored like gy, 16-byte aligned
+    if (!(K > 0 && y && dtype_y == dtype_g && !(reinterpret_cast<uintptr_t>(y) & 15))) y = nullptr;
     hipStream_t st = tpg_stream(stream);
-    float *part = static_cast<float *>(ws);
-    float *c12 = part + (size_t)BN_MAX_BLOCKS * 2 * C;
+    float *wsf = static_cast<float *>(ws);
+    float *c12 = wsf + WS_HEAD + (size_t)BN_MAX_BLOCKS * 2 * C;
     const int ne = (dtype_in == TPG_DTYPE_BF16 || dtype_g == TPG_DTYPE_BF16) ? 8 : 4;
     const int rpi = BN_THREADS / (C / ne);
     const long long rows_g = K > 0 ? P / K : P;
-    const int G = stats_blocks(rows_g, rpi);
-    const int GA = K > 0 ? row_blocks(rows_g, rpi, 1, 8192) : row_blocks(P, rpi, 4, 4096);
+    const int G = K > 0 ? row_blocks(rows_g, rpi, TPG_BN_YRED_ROWS, BN_MAX_BLOCKS) : stats_blocks(rows_g, rpi);
+    const int GA = K > 0 ? row_blocks(rows_g, rpi, 1, TPG_BN_GROUP_CAP) : row_blocks(P, rpi, TPG_BN_APPLY_ROWS, TPG_BN_APPLY_CAP);
     // no batch statistics and no affine gradients wanted (pure activation [+max]): dx = a * g,
     // nothing to reduce
-    const bool need_reduce = (training || dgamma || dbeta) && phase != TPG_BN_PHASE_APPLY;
+    const bool wanted = training || dgamma || dbeta;
+    const bool need_reduce = wanted && phase != TPG_BN_PHASE_APPLY;
     const bool do_apply = phase != TPG_BN_PHASE_STATS;
-    if (!(training || dgamma || dbeta) && phase != TPG_BN_PHASE_APPLY && hipMemsetAsync(c12, 0, sizeof(float) * 2 * (size_t)C, st) != hipSuccess)
-        return TPG_ERR_LAUNCH;
+    const float *c12_arg = wanted ? c12 : nullptr;     // absent constants read as zero
+    const int gu = group_unroll(K);
+#define TPG_BN_BWD_APPLY_MAX(TI, TG, U)                                                                     \
+    hipLaunchKernelGGL((rowbn_bwd_apply_max_kernel<TI, TG, U>), dim3(GA), dim3(BN_THREADS), 0, st, gg, xx, argmax, \
+                       rows_g, K, C, mean, rstd, gamma, beta, slope, c12_arg, static_cast<TI *>(dx))
 #define TPG_BN_BWD(TI, TG)                                                                                  \
     do {                                                                                                    \
         const TI *xx = static_cast<const TI *>(x);                                                          \
         const TG *gg = static_cast<const TG *>(gy);                                                         \
         if (!need_reduce) {                                                                                 \
-        } else if (from_y)                                                                                  \
-            hipLaunchKernelGGL((rowbn_bwd_reduce_max_y_kernel<TI, TG>), dim3(G), dim3(BN_THREADS), 0, st, gg, \
+        } else if (K > 0)                                                                                   \
+            hipLaunchKernelGGL((rowbn_bwd_reduce_max_kernel<TI, TG>), dim3(G), dim3(BN_THREADS), 0, st, gg, \
                                static_cast<const TG *>(y), xx, argmax, rows_g, K, C, mean, rstd, gamma, beta, \
-                               slope, part);                                                                \
-        else if (K > 0)                                                                                     \
-            hipLaunchKernelGGL((rowbn_bwd_reduce_max_kernel<TI, TG>), dim3(G), dim3(BN_THREADS), 0, st, gg, xx, \
-                               argmax, rows_g, K, C, mean, rstd, gamma, beta, slope, part);                 \
+                               slope, wsf);                                                                 \
         else                                                                                                \
             hipLaunchKernelGGL((rowbn_bwd_reduce_kernel<TI, TG>), dim3(G), dim3(BN_THREADS), 0, st, gg, xx, P, C, \
-                               mean, rstd, gamma, beta, slope, part);                                       \
+                               mean, rstd, gamma, beta, slope, wsf);                                        \
         if (need_reduce)                                                                                    \
-            hipLaunchKernelGGL(rowbn_bwd_finalize_kernel, dim3((C + FIN_CH - 1) / FIN_CH), dim3(BN_THREADS), 0, st, part, G, P, C, \
-                               training, dgamma, dbeta, c12);                                               \
-        if (do_apply)                                                                                       \
-            hipLaunchKernelGGL((rowbn_bwd_apply_kernel<TI, TG>), dim3(GA), dim3(BN_THREADS), 0, st, gg, xx, argmax, \
-                               P, K, C, mean, rstd, gamma, beta, slope, c12, static_cast<TI *>(dx));      \
+            hipLaunchKernelGGL(rowbn_bwd_finalize_kernel, dim3((C + FIN_CH - 1) / FIN_CH), dim3(BN_THREADS), 0, st, \
+                               wsf, G, P, C, training, dgamma, dbeta, c12);                                 \
+        if (!do_apply) {                                                                                    \
+        } else if (K > 0) {                                                                                 \
+            if (gu == 4) TPG_BN_BWD_APPLY_MAX(TI, TG, 4);                                                   \
+            else if (gu == 2) TPG_BN_BWD_APPLY_MAX(TI, TG, 2);                                              \
+            else TPG_BN_BWD_APPLY_MAX(TI, TG, 1);                                                           \
+        } else                                                                                              \
+            hipLaunchKernelGGL((rowbn_bwd_apply_kernel<TI, TG>), dim3(GA), dim3(BN_THREADS), 0, st, gg, xx, P, C, \
+                               mean, rstd, gamma, beta, slope, c12_arg, static_cast<TI *>(dx));            \
     } while (0)
     if (dtype_in == TPG_DTYPE_F32 && dtype_g == TPG_DTYPE_F32) TPG_BN_BWD(float, float);
     else if (dtype_in == TPG_DTYPE_F32) TPG_BN_BWD(float, __hip_bfloat16);
     else if (dtype_g == TPG_DTYPE_F32) TPG_BN_BWD(__hip_bfloat16, float);
     else TPG_BN_BWD(__hip_bfloat16, __hip_bfloat16);
 #undef TPG_BN_BWD
+#undef TPG_BN_BWD_APPLY_MAX
     TPG_RETURN_IF_LAUNCH_FAILED();
     return TPG_OK;
 }

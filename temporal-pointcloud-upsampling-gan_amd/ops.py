@@ -245,9 +245,9 @@ class HipBackend:
                    _ptr(idx), B, N, SK, _ptr(offs), _ptr(lst))
         return offs, lst
 
-    def rowcombine_bwd(self, gout, idx, E, mode, N, slope, in_dtype):
+    def rowcombine_bwd(self, gout, idx, E, mode, N, slope, in_dtype, inverse=None):
         B, S, K, Cc = gout.shape
-        offs, lst = self.invert_index(idx, N)
+        offs, lst = inverse if inverse is not None else self.invert_index(idx, N)
         gU = torch.empty((B, N, Cc), dtype=in_dtype, device=gout.device)
         gQE = torch.empty((B, S, Cc), dtype=in_dtype, device=gout.device) if mode != 0 else None
         nbytes = (gout.element_size() * B * S * K * Cc * (2 if mode == 1 else 1) + 8 * B * S * K
@@ -266,7 +266,7 @@ class HipBackend:
         ws = self._ws.get(key)
         need = self.lib.tpg_rowbn_workspace_bytes(max(C_, 256)) // 4
         if ws is None or ws.numel() < need:
-            ws = torch.empty(need, dtype=torch.float32, device=x.device)
+            ws = torch.zeros(need, dtype=torch.float32, device=x.device)
             self._ws[key] = ws
         return ws
 
@@ -608,10 +608,11 @@ ROW_GATHER, ROW_SUB, ROW_EDGE = 0, 1, 2
 
 class _RowCombine(torch.autograd.Function):
     @staticmethod
-    def forward(ctx, U, QE, idx, mode, slope, out_dtype):
+    def forward(ctx, U, QE, idx, mode, slope, out_dtype, inverse):
         be = backend_for(U)
         out = be.rowcombine_fwd(U, QE, idx, mode, slope, out_dtype)
         ctx.save_for_backward(idx, QE if mode == ROW_EDGE else None)
+        ctx.inverse = inverse          # (offs, lst) int32 tensors prepared ahead of time, or None
         ctx.mode, ctx.slope, ctx.N, ctx.in_dtype = mode, slope, U.shape[1], U.dtype
         ctx.has_q = QE is not None
         return out
@@ -622,8 +623,9 @@ class _RowCombine(torch.autograd.Function):
         gout = gout.contiguous()
         if gout.dtype not in _DTYPE_CODE:
             gout = gout.float()
-        gU, gQE = backend_for(gout).rowcombine_bwd(gout, idx, E, ctx.mode, ctx.N, ctx.slope, ctx.in_dtype)
-        return gU, (gQE if ctx.has_q else None), None, None, None, None
+        kw = {} if ctx.inverse is None else {"inverse": ctx.inverse}
+        gU, gQE = backend_for(gout).rowcombine_bwd(gout, idx, E, ctx.mode, ctx.N, ctx.slope, ctx.in_dtype, **kw)
+        return gU, (gQE if ctx.has_q else None), None, None, None, None, None
 
 
 def row_combine(U, QE, idx, mode, slope=0.2, out_dtype=None):
@@ -647,7 +649,22 @@ def row_combine(U, QE, idx, mode, slope=0.2, out_dtype=None):
             _need(idx.shape[1] == U.shape[1], "EDGE mode needs S == N")
     ne = 4 if (U.dtype == torch.float32 and out_dtype == torch.float32) else 8
     _need(U.shape[2] % ne == 0, f"channel count {U.shape[2]} must be a multiple of {ne}")
-    return _RowCombine.apply(U, QE, idx, mode, float(slope), out_dtype)
+    inv = getattr(idx, "_tpg_inverse", None)        # see attach_inverse
+    inverse = inv[1:] if inv is not None and inv[0] == U.shape[1] else None
+    return _RowCombine.apply(U, QE, idx, mode, float(slope), out_dtype, inverse)
+
+
+def attach_inverse(idx, N):
+    """Prepare the inverted index of a neighbour list idx (B,S,K) int32 into N source rows NOW
+    (on the current stream) and hang it on the tensor: `row_combine` hands it to its backward,
+    which then skips its own tpg_invert_index launch.  Index-only work like FPS and the ball
+    query, so an index plan can take it off the critical path.  Returns idx."""
+    _need(idx.dtype == torch.int32 and idx.dim() == 3 and idx.is_contiguous(), "idx must be contiguous (B,S,K) int32")
+    be = backend_for(idx)
+    if hasattr(be, "invert_index"):
+        offs, lst = be.invert_index(idx, int(N))
+        idx._tpg_inverse = (int(N), offs, lst)
+    return idx
 
 
 # ------------------------------------------------ fused BatchNorm + LeakyReLU (+ max over K)

@@ -274,6 +274,8 @@ class _PointnetSAModuleBase(nn.Module):
         new_xyz = ops.gather_operation(xyz.transpose(1, 2).contiguous(), centres).transpose(1, 2).contiguous()
         g = self.groupers[0]
         idx = ops.ball_query(g.radius, g.nsample, xyz, new_xyz)
+        if rows_first():
+            ops.attach_inverse(idx, xyz.shape[1])       # for the backward of the row gather
         return centres, new_xyz, idx
 
     def _first_layer(self, grouper, mlp, xyz, new_xyz, feat_rows, idx=None):
@@ -472,9 +474,13 @@ class FlowModule(nn.Module):
 
     def pair_indices(self, pos_rows_lst, cutoff):
         """Neighbour lists of the frame pairs (l, l+1): positions only, shared by every depth."""
-        return [ball_query_wrapper(cutoff, FlowEmbedding.NSAMPLE, pos_rows_lst[l].detach(),
-                                   pos_rows_lst[l + 1].detach()).to(torch.int32).contiguous()
-                for l in range(len(pos_rows_lst) - 1)]
+        pairs = [ball_query_wrapper(cutoff, FlowEmbedding.NSAMPLE, pos_rows_lst[l].detach(),
+                                    pos_rows_lst[l + 1].detach()).to(torch.int32).contiguous()
+                 for l in range(len(pos_rows_lst) - 1)]
+        if rows_first():
+            for l, idx in enumerate(pairs):               # for the backward of the row gather
+                ops.attach_inverse(idx, pos_rows_lst[l + 1].shape[1])
+        return pairs
 
     def forward_rows(self, feat_rows_lst, pos_rows_lst, cutoff, pair_idx=None):
         """Lists of (B,N,C) / (B,N,3) rows -> (B,N,out) rows."""
@@ -544,7 +550,8 @@ def run_index_plan(make_plan, stream):
 def _plan_tensors(obj):
     """Every tensor inside a (nested) plan / tuple / list / dict."""
     if torch.is_tensor(obj):
-        return [obj]
+        inv = getattr(obj, "_tpg_inverse", None)         # ops.attach_inverse
+        return [obj] + ([inv[1], inv[2]] if inv is not None else [])
     if isinstance(obj, dict):
         obj = list(obj.values())
     if isinstance(obj, (list, tuple)):

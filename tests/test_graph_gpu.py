@@ -42,7 +42,9 @@ def test_graph_replay_equals_eager(segmented):
     A = _build(dev)
     Bm = copy.deepcopy(A)
     oa, ob = _optims(*A), _optims(*Bm)
-    clips = [fluid_clip(2, 1024, 8, 3, seed=s, device=dev) for s in (1, 2)]
+    # batch 4: with 2 clips the head's BatchNorm1d sees xhat = +-1 exactly, everything upstream
+    # of it has an analytically zero gradient and the comparison would be of amplified round-off
+    clips = [fluid_clip(4, 1024, 8, 3, seed=s, device=dev) for s in (1, 2)]
     init = [[p.detach().clone() for p in m.parameters()] for m in A]
     stepper = GraphedFluidStep(Bm[0], Bm[1], Bm[2], ob, OPT, clips[0][0], clips[0][1], 1.0, None, None,
                                segmented=segmented)
@@ -69,7 +71,8 @@ def test_graph_replay_equals_eager(segmented):
         db = torch.cat([(p - q).reshape(-1) for p, q in zip(mb.parameters(), m0)])
         assert float(da.norm()) > 0
         rel = float((da - db).norm() / da.norm())
-        assert rel <= 5e-2, rel
+        print("relative L2 difference of the parameter deltas:", rel)
+        assert rel <= 2e-2, rel
     # later steps are not comparable number for number (an untrained generator's near-coincident
     # points make FPS / kNN decisions chaotic under 1e-7 differences); the replay must simply keep
     # working in the static regime, for G-only (odd) and G+D (even) iterations alike
