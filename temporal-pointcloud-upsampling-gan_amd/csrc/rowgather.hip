@@ -71,18 +71,38 @@ template <typename TA, typename TB> struct Elems {
 };
 
 // ------------------------------------------------------------------ forward
+// Tunables (tools/tune_rowcombine.py)
+#ifndef TPG_RC_FWD_U
+#define TPG_RC_FWD_U 1          // output chunks per thread and iteration (independent load chains)
+#endif
+#ifndef TPG_RC_FWD_CAP
+#define TPG_RC_FWD_CAP 16384    // most workgroups of a forward launch
+#endif
+#ifndef TPG_RC_BWD_CAP
+#define TPG_RC_BWD_CAP 4096     // most workgroups of a backward launch
+#endif
+
+// One output chunk = idx read -> row read(s) -> store: a dependent chain of two global loads.  A
+// thread can carry TPG_RC_FWD_U chains at once (all index reads, then all row reads, then the
+// arithmetic and the stores).  Measured (tools/tune_rowcombine.py): the source rows are L2
+// resident (a cloud's first-layer output is a few MB), the kernel is bound by its output
+// writes (~3 TB/s), and plain occupancy -- one chain per thread, 64 thin workgroups per CU --
+// hides the chain better than batching does (U = 4: -7 %, U = 8: -20 %); hence the defaults.
 template <typename TI, typename TO, int MODE>
 __global__ __launch_bounds__(256) void rowcombine_fwd_kernel(
     const TI *__restrict__ U, const TI *__restrict__ QE, const int32_t *__restrict__ idx, int N, int S,
     int K, int C, float slope, TO *__restrict__ out, unsigned total) {
     constexpr int NE = Elems<TI, TO>::NE;
+    constexpr int UF = TPG_RC_FWD_U;
     using In = RowIO<TI, NE>;
     using Out = RowIO<TO, NE>;
     const unsigned cpr = (unsigned)C / NE;  // 16-byte chunks per row
-    for (unsigned t = blockIdx.x * 256u + threadIdx.x; t < total; t += gridDim.x * 256u) {
-        const unsigned row = t / cpr;            // flat (b,s,k)
-        const unsigned col = (t - row * cpr) * NE;
-        const unsigned bs = row / (unsigned)K;   // flat (b,s)
+    const unsigned stride = gridDim.x * 256u;
+    unsigned t = blockIdx.x * 256u + threadIdx.x;
+    auto one = [&](unsigned tt) {
+        const unsigned row = tt / cpr;            // flat (b,s,k)
+        const unsigned col = (tt - row * cpr) * NE;
+        const unsigned bs = row / (unsigned)K;    // flat (b,s)
         const unsigned b = bs / (unsigned)S;
         const int n = tpg_clamp_idx(idx[row], N);
         float u[NE];
@@ -103,7 +123,43 @@ __global__ __launch_bounds__(256) void rowcombine_fwd_kernel(
             }
         }
         Out::store(out + (size_t)row * C + col, u);
+    };
+    for (; (unsigned long long)t + (unsigned long long)(UF - 1) * stride < total; t += UF * stride) {
+        unsigned row[UF], col[UF], bs[UF], b[UF];
+        int n[UF];
+#pragma unroll
+        for (int j = 0; j < UF; ++j) {
+            const unsigned tt = t + j * stride;
+            row[j] = tt / cpr;
+            col[j] = (tt - row[j] * cpr) * NE;
+            bs[j] = row[j] / (unsigned)K;
+            b[j] = bs[j] / (unsigned)S;
+            n[j] = idx[row[j]];
+        }
+        float u[UF][NE], q[UF][NE], en[UF][NE];
+#pragma unroll
+        for (int j = 0; j < UF; ++j) {
+            n[j] = tpg_clamp_idx(n[j], N);
+            In::load(U + ((size_t)b[j] * N + n[j]) * C + col[j], u[j]);
+            if (MODE != MODE_GATHER) In::load(QE + (size_t)bs[j] * C + col[j], q[j]);      // centre row
+            if (MODE == MODE_EDGE) In::load(QE + ((size_t)b[j] * N + n[j]) * C + col[j], en[j]);
+        }
+#pragma unroll
+        for (int j = 0; j < UF; ++j) {
+            if (MODE == MODE_SUB) {
+#pragma unroll
+                for (int i = 0; i < NE; ++i) u[j][i] = u[j][i] - q[j][i];
+            } else if (MODE == MODE_EDGE) {
+#pragma unroll
+                for (int i = 0; i < NE; ++i) {
+                    const float d = en[j][i] - q[j][i];
+                    u[j][i] = u[j][i] + (d > 0.0f ? d : d * slope);
+                }
+            }
+            Out::store(out + (size_t)row[j] * C + col[j], u[j]);
+        }
     }
+    for (; t < total; t += stride) one(t);
 }
 
 // ------------------------------------------------------------------ inverted index
@@ -187,7 +243,30 @@ __global__ __launch_bounds__(256) void rowcombine_bwd_kernel(
         for (int i = 0; i < NE; ++i) { acc[i] = 0.0f; accE[i] = 0.0f; }
         if (MODE == MODE_EDGE) In::load(E + (size_t)drow * C + col, en);
         const int p1 = of[n + 1];
-        for (int p = of[n]; p < p1; ++p) {
+        int p = of[n];
+        // entries four at a time: the 4 list reads, then the 4 (+4) row reads are independent
+        // loads in flight together; the sums keep the sequential order of the entries
+        for (; p + 4 <= p1; p += 4) {
+            int e[4];
+#pragma unroll
+            for (int u = 0; u < 4; ++u) e[u] = ls[p + u];
+            float g[4][NE], es[4][NE];
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                Gr::load(go + (size_t)e[u] * C, g[u]);
+                if (MODE == MODE_EDGE) In::load(E + ((size_t)b * N + (unsigned)e[u] / (unsigned)K) * C + col, es[u]);
+            }
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+#pragma unroll
+                for (int i = 0; i < NE; ++i) acc[i] += g[u][i];
+                if (MODE == MODE_EDGE) {
+#pragma unroll
+                    for (int i = 0; i < NE; ++i) accE[i] += (en[i] - es[u][i] > 0.0f) ? g[u][i] : g[u][i] * slope;
+                }
+            }
+        }
+        for (; p < p1; ++p) {
             const int e = ls[p];
             float g[NE];
             Gr::load(go + (size_t)e * C, g);
@@ -202,7 +281,23 @@ __global__ __launch_bounds__(256) void rowcombine_bwd_kernel(
         }
         if (MODE == MODE_EDGE) {
             // this row as a CENTRE: -sum_k g * lrelu'(E[nbr] - E[n])   (S == N)
-            for (int k = 0; k < K; ++k) {
+            int k = 0;
+            for (; k + 4 <= K; k += 4) {
+                int nb[4];
+#pragma unroll
+                for (int u = 0; u < 4; ++u) nb[u] = tpg_clamp_idx(idx[(size_t)b * SK + (size_t)n * K + k + u], N);
+                float g[4][NE], eb[4][NE];
+#pragma unroll
+                for (int u = 0; u < 4; ++u) {
+                    Gr::load(go + ((size_t)n * K + k + u) * C, g[u]);
+                    In::load(E + ((size_t)b * N + nb[u]) * C + col, eb[u]);
+                }
+#pragma unroll
+                for (int u = 0; u < 4; ++u)
+#pragma unroll
+                    for (int i = 0; i < NE; ++i) accE[i] -= (eb[u][i] - en[i] > 0.0f) ? g[u][i] : g[u][i] * slope;
+            }
+            for (; k < K; ++k) {
                 const size_t e = (size_t)n * K + k;
                 const int nb = tpg_clamp_idx(idx[(size_t)b * SK + e], N);
                 float g[NE], eb[NE];
@@ -229,7 +324,17 @@ __global__ __launch_bounds__(256) void rowsum_neg_kernel(const TG *__restrict__ 
         float acc[NE];
 #pragma unroll
         for (int i = 0; i < NE; ++i) acc[i] = 0.0f;
-        for (int k = 0; k < K; ++k) {
+        int k = 0;
+        for (; k + 4 <= K; k += 4) {           // four independent row reads in flight, sequential sums
+            float g[4][NE];
+#pragma unroll
+            for (int u = 0; u < 4; ++u) RowIO<TG, NE>::load(gout + ((size_t)bs * K + k + u) * C + col, g[u]);
+#pragma unroll
+            for (int u = 0; u < 4; ++u)
+#pragma unroll
+                for (int i = 0; i < NE; ++i) acc[i] -= g[u][i];
+        }
+        for (; k < K; ++k) {
             float g[NE];
             RowIO<TG, NE>::load(gout + ((size_t)bs * K + k) * C + col, g);
 #pragma unroll
@@ -239,9 +344,9 @@ __global__ __launch_bounds__(256) void rowsum_neg_kernel(const TG *__restrict__ 
     }
 }
 
-unsigned grid_for(unsigned total) {
-    const unsigned blocks = (total + 255u) / 256u;
-    return blocks < 1u ? 1u : (blocks > 16384u ? 16384u : blocks);  // 64 workgroups per CU, then stride
+unsigned grid_for(unsigned total, unsigned per_thread = 1u, unsigned cap = 16384u) {
+    const unsigned blocks = (total + 256u * per_thread - 1u) / (256u * per_thread);
+    return blocks < 1u ? 1u : (blocks > cap ? cap : blocks);
 }
 
 bool aligned16(const void *a, const void *b, const void *c, const void *d) {
@@ -258,7 +363,7 @@ int fwd_go(const void *U, const void *QE, const int32_t *idx, int mode, int B, i
     const unsigned long long total64 = (unsigned long long)B * S * K * (C / NE);
     if (total64 >= 0x7fffffffULL) return TPG_ERR_ARG;
     const unsigned total = (unsigned)total64;
-    const dim3 g(grid_for(total)), blk(256);
+    const dim3 g(grid_for(total, TPG_RC_FWD_U, TPG_RC_FWD_CAP)), blk(256);
     const TI *u = static_cast<const TI *>(U), *q = static_cast<const TI *>(QE);
     TO *o = static_cast<TO *>(out);
     if (mode == MODE_GATHER)
@@ -279,7 +384,7 @@ int bwd_go(const void *gout, const int32_t *idx, const int32_t *offs, const int3
     const unsigned long long totq64 = (unsigned long long)B * S * (C / NE);
     if (total64 >= 0x7fffffffULL || totq64 >= 0x7fffffffULL) return TPG_ERR_ARG;
     const unsigned total = (unsigned)total64;
-    const dim3 g(grid_for(total)), blk(256);
+    const dim3 g(grid_for(total, 1u, TPG_RC_BWD_CAP)), blk(256);
     const TG *go = static_cast<const TG *>(gout);
     const TI *e = static_cast<const TI *>(E);
     TI *gu = static_cast<TI *>(gU), *gq = static_cast<TI *>(gQE);

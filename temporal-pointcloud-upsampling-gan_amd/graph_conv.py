@@ -349,7 +349,13 @@ class IDGCNLayer(nn.Module):
         low = rows_seq(self.btn, x).contiguous()                        # (B,N,C/4)
         _, idx = ops.neighbour_search(low, low, 9)
         local = ops.row_combine(low, None, idx.to(torch.int32), ops.ROW_GATHER)   # (B,N,9,C/4)
-        out = torch.cat([local.max(2)[0], self.GCN1.forward_rows(low), self.GCN2.forward_rows(low)], dim=-1)
+        B, N, k, q = local.shape
+        if q % 8 == 0 and low.dtype in (torch.float32, torch.bfloat16):
+            # max over the 9 neighbours with a one-byte arg-max and a one-pass backward
+            local_max = ops.row_act_max(local.view(B * N * k, q), 1.0, k).view(B, N, q)
+        else:
+            local_max = local.max(2)[0]
+        out = torch.cat([local_max, self.GCN1.forward_rows(low), self.GCN2.forward_rows(low)], dim=-1)
         out = rows_seq(self.decoder, out)
         if self.use_layernorm:
             out = self.layernorm(out)

@@ -281,6 +281,7 @@ class _PointnetSAModuleBase(nn.Module):
     def _first_layer(self, grouper, mlp, xyz, new_xyz, feat_rows, idx=None):
         """Rows of the first conv's output for every grouped position: (B,S,ns,C1)."""
         conv = mlp[0]
+        rows_dtype = amp_dtype(xyz)           # decided OUTSIDE the fp32 island below
         with no_autocast(xyz):
             W = conv_weight2d(conv).float()
             src = xyz if feat_rows is None else torch.cat([xyz, feat_rows.float()], dim=-1)
@@ -293,8 +294,8 @@ class _PointnetSAModuleBase(nn.Module):
                 idx = ops.ball_query(grouper.radius, grouper.nsample, xyz, new_xyz)
             if grouper.use_xyz:
                 Q = rows_matmul(new_xyz, W[:, :3])                  # centre term of (xyz_j - c_i)
-                return ops.row_combine(U, Q, idx, ops.ROW_SUB, out_dtype=amp_dtype(xyz))
-            return ops.row_combine(U, None, idx, ops.ROW_GATHER, out_dtype=amp_dtype(xyz))
+                return ops.row_combine(U, Q, idx, ops.ROW_SUB, out_dtype=rows_dtype)
+            return ops.row_combine(U, None, idx, ops.ROW_GATHER, out_dtype=rows_dtype)
 
     def forward_rows(self, xyz, feat_rows, plan=None):
         """xyz (B,N,3), feat_rows (B,N,C)|None -> new_xyz (B,npoint,3)|None, (B,npoint,C') rows.
