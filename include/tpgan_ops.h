@@ -142,18 +142,28 @@ int tpg_rowcombine_bwd(const void *gout, const int32_t *idx, const int32_t *offs
  * *num_batches_tracked (may be NULL) is incremented, as nn.BatchNorm's forward does.
  * training == 0: mean / rstd are inputs (the caller derives them from the running statistics);
  * both NULL = identity statistics (mean 0, rstd 1: a pure activation [+ max]).
- * ws: tpg_rowbn_workspace_bytes(C) bytes of scratch, 16-byte aligned, not shared by launches that
- * may run concurrently.  gamma / beta may be NULL (1 / 0).
+ * ws: tpg_rowbn_workspace_bytes(C, nseg) bytes of scratch, 16-byte aligned, not shared by launches
+ * that may run concurrently.  gamma / beta may be NULL (1 / 0).
+ * mean_shift (C, may be NULL): a per-channel constant the caller has LEFT OUT of x -- the bias of
+ * the preceding 1x1 conv.  Training-mode BatchNorm(x + b) == BatchNorm(x), so the bias add (a full
+ * pass, or a GEMM epilogue the batched GEMM does not have) is skipped; only the running mean sees
+ * b: it is updated with mean(x) + mean_shift.  (Eval mode: the caller passes mean - b.)
+ * nseg >= 1 SEGMENTS: the P rows are nseg equal consecutive blocks, each an independent call of
+ * the same module (the T frames of a clip, the fake and the real batch -- discriminator.py runs
+ * them one after the other): statistics per segment (mean / rstd are (nseg, C)), running
+ * statistics and num_batches_tracked updated segment after segment in that order, dgamma / dbeta
+ * summed over the segments.  K > 0 groups never straddle segments (K | P/nseg).
  * phase: TPG_BN_PHASE_ALL, or the reduction part / the streaming part alone (two calls with the
  * same arguments and workspace = one ALL call; lets a profiler time each kernel by itself). */
 #define TPG_BN_PHASE_ALL 0
 #define TPG_BN_PHASE_STATS 1
 #define TPG_BN_PHASE_APPLY 2
-size_t tpg_rowbn_workspace_bytes(int C);
+size_t tpg_rowbn_workspace_bytes(int C, int nseg);
 int tpg_rowbn_fwd(const void *x, int dtype_in, long long P, int K, int C, float eps, float momentum,
                   int training, float *running_mean, float *running_var, long long *num_batches_tracked,
-                  const float *gamma, const float *beta, float slope, float *mean, float *rstd, void *y,
-                  int dtype_out, uint8_t *argmax, void *ws, int phase, void *stream);
+                  const float *mean_shift, const float *gamma, const float *beta, float slope, float *mean,
+                  float *rstd, void *y,
+                  int dtype_out, uint8_t *argmax, void *ws, int nseg, int phase, void *stream);
 /* gy: (P,C) for K == 0, (P/K,C) for K > 0, of dtype_g; dx (P,C) of dtype_in; dgamma / dbeta (C) f32
  * (may be NULL).  y / dtype_y (K > 0 only, may be NULL): the forward's output; with it the
  * per-channel sums of the max variant are taken from (gy, y) alone -- the pre-activation of the
@@ -163,7 +173,7 @@ int tpg_rowbn_fwd(const void *x, int dtype_in, long long P, int K, int C, float 
 int tpg_rowbn_bwd(const void *gy, int dtype_g, const void *x, int dtype_in, const uint8_t *argmax,
                   const void *y, int dtype_y, long long P, int K, int C, int training, const float *mean,
                   const float *rstd, const float *gamma, const float *beta, float slope, float *dgamma,
-                  float *dbeta, void *dx, void *ws, int phase, void *stream);
+                  float *dbeta, void *dx, void *ws, int nseg, int phase, void *stream);
 
 /* ---- fused spectral normalisation of a (R x Cn) conv / linear weight ------------------------
  * torch.nn.utils.spectral_norm's forward pre-hook (n_power_iterations = 1) on every conv and

@@ -86,30 +86,47 @@ class OracleBackend:
 
     # ---- fused BatchNorm + act (+max) on rows ---------------------------------------------
     def rowbn_fwd(self, x, K, eps, momentum, training, running_mean, running_var, gamma, beta, slope, mean,
-                  rstd, out_dtype, num_batches_tracked=None):
+                  rstd, out_dtype, num_batches_tracked=None, nseg=1, mean_shift=None):
+        """nseg segments = nseg consecutive calls on equal row blocks (include/tpgan_ops.h)."""
         Cc = x.shape[1]
         if not training and mean is None:            # identity statistics
-            mean, rstd = torch.zeros(Cc), torch.ones(Cc)
-        y, m, r, arg = R.rowbn_fwd(_np(x.float()), K, eps, _np(gamma), _np(beta), slope, training,
-                                   None if training else _np(mean), None if training else _np(rstd))
-        if training:
-            mean.copy_(_t(m))
-            rstd.copy_(_t(r))
-            if num_batches_tracked is not None:
-                num_batches_tracked.add_(1)
-            if running_mean is not None:
-                P = x.shape[0]
-                var = (1.0 / (_t(r).double() ** 2) - eps) * (P / max(P - 1, 1))
-                running_mean.mul_(1 - momentum).add_(momentum * _t(m))
-                running_var.mul_(1 - momentum).add_((momentum * var).float())
-        return _t(y).to(out_dtype), (None if arg is None else _t(arg))
+            mean, rstd = torch.zeros(1, Cc), torch.ones(1, Cc)
+        Ps = x.shape[0] // nseg
+        ys, args = [], []
+        for sg in range(nseg):
+            xs = x[sg * Ps:(sg + 1) * Ps]
+            ms = None if training else _np(mean.reshape(-1, Cc)[0])
+            rs = None if training else _np(rstd.reshape(-1, Cc)[0])
+            y, m, r, arg = R.rowbn_fwd(_np(xs.float()), K, eps, _np(gamma), _np(beta), slope, training, ms, rs)
+            if training:
+                mean.reshape(-1, Cc)[sg].copy_(_t(m))
+                rstd.reshape(-1, Cc)[sg].copy_(_t(r))
+                if num_batches_tracked is not None:
+                    num_batches_tracked.add_(1)
+                if running_mean is not None:
+                    var = (1.0 / (_t(r).double() ** 2) - eps) * (Ps / max(Ps - 1, 1))
+                    running_mean.mul_(1 - momentum).add_(momentum * (_t(m) + (0 if mean_shift is None else mean_shift)))
+                    running_var.mul_(1 - momentum).add_((momentum * var).float())
+            ys.append(_t(y))
+            args.append(None if arg is None else _t(arg))
+        y = torch.cat(ys, 0).to(out_dtype)
+        return y, (None if args[0] is None else torch.cat(args, 0))
 
-    def rowbn_bwd(self, gy, x, arg, K, training, mean, rstd, gamma, beta, slope, need_affine, y=None):
+    def rowbn_bwd(self, gy, x, arg, K, training, mean, rstd, gamma, beta, slope, need_affine, y=None, nseg=1):
+        Cc = x.shape[1]
         if mean is None:
-            mean, rstd = torch.zeros(x.shape[1]), torch.ones(x.shape[1])
-        dx, dg, db = R.rowbn_bwd(_np(gy.float()), _np(x.float()), _np(arg), K, training, _np(mean), _np(rstd),
-                                 _np(gamma), _np(beta), slope)
-        return _t(dx).to(x.dtype), (_t(dg) if need_affine else None), (_t(db) if need_affine else None)
+            mean, rstd = torch.zeros(1, Cc), torch.ones(1, Cc)
+        mean, rstd = mean.reshape(-1, Cc), rstd.reshape(-1, Cc)
+        Ps, Gs = x.shape[0] // nseg, gy.shape[0] // nseg
+        dxs, dg, db = [], 0.0, 0.0
+        for sg in range(nseg):
+            a = None if arg is None else _np(arg[sg * Gs:(sg + 1) * Gs])
+            dx, g_, b_ = R.rowbn_bwd(_np(gy[sg * Gs:(sg + 1) * Gs].float()), _np(x[sg * Ps:(sg + 1) * Ps].float()), a, K,
+                                     training, _np(mean[min(sg, mean.shape[0] - 1)]),
+                                     _np(rstd[min(sg, rstd.shape[0] - 1)]), _np(gamma), _np(beta), slope)
+            dxs.append(_t(dx))
+            dg, db = dg + _t(g_), db + _t(b_)
+        return torch.cat(dxs, 0).to(x.dtype), (dg if need_affine else None), (db if need_affine else None)
 
 
     # ---- fused spectral norm ------------------------------------------------------------

@@ -33,8 +33,8 @@ SIGNATURES = {
     "tpg_rowcombine_fwd": [_P, _P, _P, _I, _I, _I, _I, _I, _I, _I, _I, _F, _P, _P],
     "tpg_invert_index": [_P, _I, _I, _I, _P, _P, _P],
     "tpg_rowcombine_bwd": [_P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _I, _I, _F, _P, _P, _P],
-    "tpg_rowbn_fwd": [_P, _I, _L, _I, _I, _F, _F, _I, _P, _P, _P, _P, _P, _F, _P, _P, _P, _I, _P, _P, _I, _P],
-    "tpg_rowbn_bwd": [_P, _I, _P, _I, _P, _P, _I, _L, _I, _I, _I, _P, _P, _P, _P, _F, _P, _P, _P, _P, _I, _P],
+    "tpg_rowbn_fwd": [_P, _I, _L, _I, _I, _F, _F, _I, _P, _P, _P, _P, _P, _P, _F, _P, _P, _P, _I, _P, _P, _I, _I, _P],
+    "tpg_rowbn_bwd": [_P, _I, _P, _I, _P, _P, _I, _L, _I, _I, _I, _P, _P, _P, _P, _F, _P, _P, _P, _P, _I, _I, _P],
     "tpg_spectral_norm_fwd": [_P, _P, _P, _I, _I, _I, _F, _P, _P, _P],
     "tpg_spectral_norm_bwd": [_P, _P, _P, _P, _P, _I, _I, _P, _P],
     "tpg_spectral_norm_multi_fwd": [_P, _I, _I, _P, _I, _F, _P],
@@ -70,7 +70,7 @@ def load():
     for name in STRING_GETTERS:
         getattr(lib, name).restype = C.c_char_p
     for name in SIZE_GETTERS:
-        getattr(lib, name).argtypes = [C.c_int]
+        getattr(lib, name).argtypes = [C.c_int, C.c_int]
         getattr(lib, name).restype = C.c_size_t
     lib.tpg_spectral_norm_multi_stride.argtypes = [C.c_int, C.c_int]
     lib.tpg_spectral_norm_multi_stride.restype = C.c_longlong

@@ -26,6 +26,10 @@
 //   * the row walk is software-pipelined: the 16-byte loads of the next U rows are in flight
 //     while the current U rows are computed (bf16 unpack, FMA, select: ~50 VALU ops per 16 B
 //     would otherwise alternate with the memory latency instead of hiding it).
+// Segments: a launch may carry `nseg` independent BatchNorm calls of the same module on equally
+// sized, consecutive blocks of rows (the T frames of a clip, the fake and the real batch): each
+// segment has its own statistics (gridDim.y = nseg), running statistics are updated segment after
+// segment exactly as the separate calls would, dgamma / dbeta are summed over the segments.
 // Rows are 16-byte vectors per lane (fp32 or bf16 storage, fp32 arithmetic); a thread owns one
 // column chunk, so per-channel constants stay in registers.  Sums are taken about a per-channel
 // pivot (the first row) to keep E[x^2]-E[x]^2 well conditioned.
@@ -241,7 +245,8 @@ __global__ __launch_bounds__(BN_THREADS) void rowbn_stats_kernel(const T *__rest
     const int cpr = C / NE, rpi = BN_THREADS / cpr;  // chunks per row, rows per iteration
     const int tid = threadIdx.x;
     const int chunk = tid % cpr, rsub = tid / cpr;
-    float *part = ws + WS_HEAD;
+    x += (size_t)blockIdx.y * P * C;                                         // this segment's rows
+    float *part = ws + WS_HEAD + (size_t)blockIdx.y * BN_MAX_BLOCKS * 2 * C;
     float acc[2][NE];
 #pragma unroll
     for (int i = 0; i < NE; ++i) { acc[0][i] = 0.0f; acc[1][i] = 0.0f; }
@@ -277,21 +282,28 @@ template <typename T>
 __global__ __launch_bounds__(BN_THREADS) void rowbn_stats_finalize_kernel(
     const T *__restrict__ x, const float *__restrict__ ws, int G, long long P, int C, float eps,
     float momentum, float *__restrict__ running_mean, float *__restrict__ running_var,
-    long long *__restrict__ num_batches_tracked, float *__restrict__ mean, float *__restrict__ rstd) {
-    int c;
-    double s, ss;
-    if (num_batches_tracked && blockIdx.x == 0 && threadIdx.x == 0) *num_batches_tracked += 1;
-    if (!finalize_sums(ws + WS_HEAD, G, C, c, s, ss)) return;
-    const double piv = Chunk<T, BnElems<T>::NE>::one(x + c);
-    const double m = s / (double)P;
-    double var = ss / (double)P - m * m;  // biased, about the pivot
-    var = var < 0.0 ? 0.0 : var;
-    mean[c] = (float)(piv + m);
-    rstd[c] = (float)(1.0 / sqrt(var + (double)eps));
-    if (running_mean) {
-        const double unbiased = P > 1 ? var * (double)P / (double)(P - 1) : var;
-        running_mean[c] = (float)((1.0 - momentum) * running_mean[c] + momentum * (piv + m));
-        running_var[c] = (float)((1.0 - momentum) * running_var[c] + momentum * unbiased);
+    long long *__restrict__ num_batches_tracked, const float *__restrict__ mean_shift, float *__restrict__ mean,
+    float *__restrict__ rstd, int nseg) {
+    if (num_batches_tracked && blockIdx.x == 0 && threadIdx.x == 0) *num_batches_tracked += nseg;
+    for (int seg = 0; seg < nseg; ++seg) {     // in call order: the running statistics chain
+        int c;
+        double s, ss;
+        const bool mine = finalize_sums(ws + WS_HEAD + (size_t)seg * BN_MAX_BLOCKS * 2 * C, G, C, c, s, ss);
+        if (mine) {
+            const double piv = Chunk<T, BnElems<T>::NE>::one(x + (size_t)seg * P * C + c);
+            const double m = s / (double)P;
+            double var = ss / (double)P - m * m;  // biased, about the pivot
+            var = var < 0.0 ? 0.0 : var;
+            mean[(size_t)seg * C + c] = (float)(piv + m);
+            rstd[(size_t)seg * C + c] = (float)(1.0 / sqrt(var + (double)eps));
+            if (running_mean) {
+                const double unbiased = P > 1 ? var * (double)P / (double)(P - 1) : var;
+                const double shift = mean_shift ? (double)mean_shift[c] : 0.0;   // see tpgan_ops.h
+                running_mean[c] = (float)((1.0 - momentum) * running_mean[c] + momentum * (piv + m + shift));
+                running_var[c] = (float)((1.0 - momentum) * running_var[c] + momentum * unbiased);
+            }
+        }
+        __syncthreads();                       // finalize_sums' LDS is reused by the next segment
     }
 }
 
@@ -305,6 +317,9 @@ __global__ __launch_bounds__(BN_THREADS) void rowbn_apply_kernel(
     const int cpr = C / NE, rpi = BN_THREADS / cpr;
     const int chunk = threadIdx.x % cpr, rsub = threadIdx.x / cpr, col = chunk * NE;
     if (rsub >= rpi) return;
+    x += (size_t)blockIdx.y * P * C;
+    y += (size_t)blockIdx.y * P * C;
+    if (mean) { mean += (size_t)blockIdx.y * C; rstd += (size_t)blockIdx.y * C; }
     float a[NE], b[NE], mu[NE];
     ld_consts<NE>(mean, col, 0.0f, mu);
     ld_consts<NE>(rstd, col, 1.0f, a);
@@ -342,6 +357,10 @@ __global__ __launch_bounds__(BN_THREADS) void rowbn_apply_max_kernel(
     const int cpr = C / NE, rpi = BN_THREADS / cpr;
     const int chunk = threadIdx.x % cpr, rsub = threadIdx.x / cpr, col = chunk * NE;
     if (rsub >= rpi) return;
+    x += (size_t)blockIdx.y * Gp * K * C;
+    y += (size_t)blockIdx.y * Gp * C;
+    arg += (size_t)blockIdx.y * Gp * C;
+    if (mean) { mean += (size_t)blockIdx.y * C; rstd += (size_t)blockIdx.y * C; }
     float a[NE], b[NE], mu[NE];
     ld_consts<NE>(mean, col, 0.0f, mu);
     ld_consts<NE>(rstd, col, 1.0f, a);
@@ -414,14 +433,25 @@ __global__ __launch_bounds__(BN_THREADS) void rowbn_bwd_finalize_kernel(const fl
                                                                         long long P, int C, int training,
                                                                         float *__restrict__ dgamma,
                                                                         float *__restrict__ dbeta,
-                                                                        float *__restrict__ c12) {
-    int c;
-    double s, sx;
-    if (!finalize_sums(ws + WS_HEAD, G, C, c, s, sx)) return;
-    if (dbeta) dbeta[c] = (float)s;
-    if (dgamma) dgamma[c] = (float)sx;
-    c12[c] = training ? (float)(s / (double)P) : 0.0f;       // eval-mode BN: no batch terms
-    c12[C + c] = training ? (float)(sx / (double)P) : 0.0f;
+                                                                        float *__restrict__ c12, int nseg) {
+    double ts = 0.0, tsx = 0.0;
+    int c = 0;
+    bool mine = false;
+    for (int seg = 0; seg < nseg; ++seg) {
+        double s, sx;
+        mine = finalize_sums(ws + WS_HEAD + (size_t)seg * BN_MAX_BLOCKS * 2 * C, G, C, c, s, sx);
+        if (mine) {
+            ts += s;                               // fixed order: segment after segment
+            tsx += sx;
+            float *cs = c12 + (size_t)seg * 2 * C;
+            cs[c] = training ? (float)(s / (double)P) : 0.0f;       // eval-mode BN: no batch terms
+            cs[C + c] = training ? (float)(sx / (double)P) : 0.0f;
+        }
+        __syncthreads();
+    }
+    if (!mine) return;
+    if (dbeta) dbeta[c] = (float)ts;
+    if (dgamma) dgamma[c] = (float)tsx;
 }
 
 template <typename TI, typename TG>
@@ -433,6 +463,10 @@ __global__ __launch_bounds__(BN_THREADS) void rowbn_bwd_reduce_kernel(
     const int cpr = C / NE, rpi = BN_THREADS / cpr;
     const int tid = threadIdx.x;
     const int chunk = tid % cpr, rsub = tid / cpr, col = chunk * NE;
+    gy += (size_t)blockIdx.y * P * C;
+    x += (size_t)blockIdx.y * P * C;
+    if (mean) { mean += (size_t)blockIdx.y * C; rstd += (size_t)blockIdx.y * C; }
+    ws += (size_t)blockIdx.y * BN_MAX_BLOCKS * 2 * C;
     float acc[2][NE];
 #pragma unroll
     for (int i = 0; i < NE; ++i) { acc[0][i] = 0.0f; acc[1][i] = 0.0f; }
@@ -480,6 +514,12 @@ __global__ __launch_bounds__(BN_THREADS) void rowbn_bwd_reduce_max_kernel(
     const int cpr = C / NE, rpi = BN_THREADS / cpr;
     const int tid = threadIdx.x;
     const int chunk = tid % cpr, rsub = tid / cpr, col = chunk * NE;
+    gy += (size_t)blockIdx.y * Gp * C;
+    if (y) y += (size_t)blockIdx.y * Gp * C;
+    x += (size_t)blockIdx.y * Gp * K * C;
+    arg += (size_t)blockIdx.y * Gp * C;
+    if (mean) { mean += (size_t)blockIdx.y * C; rstd += (size_t)blockIdx.y * C; }
+    ws += (size_t)blockIdx.y * BN_MAX_BLOCKS * 2 * C;
     float acc[2][NE];
 #pragma unroll
     for (int i = 0; i < NE; ++i) { acc[0][i] = 0.0f; acc[1][i] = 0.0f; }
@@ -537,6 +577,11 @@ __global__ __launch_bounds__(BN_THREADS) void rowbn_bwd_apply_kernel(
     const int cpr = C / NE, rpi = BN_THREADS / cpr;
     const int chunk = threadIdx.x % cpr, rsub = threadIdx.x / cpr, col = chunk * NE;
     if (rsub >= rpi) return;
+    gy += (size_t)blockIdx.y * P * C;
+    x += (size_t)blockIdx.y * P * C;
+    dx += (size_t)blockIdx.y * P * C;
+    if (mean) { mean += (size_t)blockIdx.y * C; rstd += (size_t)blockIdx.y * C; }
+    if (c12) c12 += (size_t)blockIdx.y * 2 * C;
     float a[NE], b[NE], mu[NE], rs[NE], c1[NE], c2[NE];
     ld_consts<NE>(mean, col, 0.0f, mu);
     ld_consts<NE>(rstd, col, 1.0f, rs);
@@ -577,6 +622,12 @@ __global__ __launch_bounds__(BN_THREADS) void rowbn_bwd_apply_max_kernel(
     const int cpr = C / NE, rpi = BN_THREADS / cpr;
     const int chunk = threadIdx.x % cpr, rsub = threadIdx.x / cpr, col = chunk * NE;
     if (rsub >= rpi) return;
+    gy += (size_t)blockIdx.y * Gp * C;
+    arg += (size_t)blockIdx.y * Gp * C;
+    x += (size_t)blockIdx.y * Gp * K * C;
+    dx += (size_t)blockIdx.y * Gp * K * C;
+    if (mean) { mean += (size_t)blockIdx.y * C; rstd += (size_t)blockIdx.y * C; }
+    if (c12) c12 += (size_t)blockIdx.y * 2 * C;
     float a[NE], b[NE], mu[NE], rs[NE], c1[NE], c2[NE];
     ld_consts<NE>(mean, col, 0.0f, mu);
     ld_consts<NE>(rstd, col, 1.0f, rs);
@@ -655,20 +706,30 @@ bool bn_shape_ok(int dtype_a, int dtype_b, int C) {
     return C > 0 && C % ne == 0 && C / 4 <= BN_THREADS;   // <= 1024 channels (column-sum layout)
 }
 bool bn_dtype_ok(int d) { return d == TPG_DTYPE_F32 || d == TPG_DTYPE_BF16; }
+// workgroups per segment of a reduction when nseg segments share the launch
+int seg_blocks(int blocks, int nseg) {
+    const int d = nseg > 4 ? 4 : nseg;
+    const int b = (blocks + d - 1) / d;
+    return b < 1 ? 1 : b;
+}
 int group_unroll(int K) { return K % 4 == 0 ? 4 : (K % 2 == 0 ? 2 : 1); }
 
 }  // namespace
 
-extern "C" size_t tpg_rowbn_workspace_bytes(int C) {
-    return sizeof(float) * (WS_HEAD + (size_t)BN_MAX_BLOCKS * 2 * C + 2 * (size_t)C);
+extern "C" size_t tpg_rowbn_workspace_bytes(int C, int nseg) {
+    if (nseg < 1) nseg = 1;
+    return sizeof(float) * (WS_HEAD + (size_t)nseg * ((size_t)BN_MAX_BLOCKS * 2 * C + 2 * (size_t)C));
 }
 
 extern "C" int tpg_rowbn_fwd(const void *x, int dtype_in, long long P, int K, int C, float eps, float momentum,
                              int training, float *running_mean, float *running_var,
-                             long long *num_batches_tracked, const float *gamma, const float *beta, float slope,
-                             float *mean, float *rstd, void *y, int dtype_out, uint8_t *argmax, void *ws, int phase,
-                             void *stream) {
-    if (P <= 0 || C <= 0 || K < 0 || K > 256 || (K > 0 && P % K)) return TPG_ERR_ARG;
+                             long long *num_batches_tracked, const float *mean_shift, const float *gamma,
+                             const float *beta, float slope,
+                             float *mean, float *rstd, void *y, int dtype_out, uint8_t *argmax, void *ws, int nseg,
+                             int phase, void *stream) {
+    if (P <= 0 || C <= 0 || K < 0 || K > 256 || nseg < 1 || nseg > 65535 || P % nseg) return TPG_ERR_ARG;
+    P /= nseg;                                    // rows per segment from here on
+    if (K > 0 && P % K) return TPG_ERR_ARG;
     if (!x || !y || !ws || (K > 0 && !argmax)) return TPG_ERR_ARG;
     if (training ? (!mean || !rstd) : ((mean == nullptr) != (rstd == nullptr))) return TPG_ERR_ARG;
     if (!bn_dtype_ok(dtype_in) || !bn_dtype_ok(dtype_out) || !bn_shape_ok(dtype_in, dtype_out, C))
@@ -681,18 +742,18 @@ extern "C" int tpg_rowbn_fwd(const void *x, int dtype_in, long long P, int K, in
         // statistics use the INPUT type's vector width
         const int ne = dtype_in == TPG_DTYPE_BF16 ? 8 : 4;
         const int rpi = BN_THREADS / (C / ne);
-        const int G = stats_blocks(P, rpi);
+        const int G = seg_blocks(stats_blocks(P, rpi), nseg);
         const dim3 fg((C + FIN_CH - 1) / FIN_CH);
         if (dtype_in == TPG_DTYPE_BF16) {
             const __hip_bfloat16 *xx = static_cast<const __hip_bfloat16 *>(x);
-            hipLaunchKernelGGL(rowbn_stats_kernel<__hip_bfloat16>, dim3(G), dim3(BN_THREADS), 0, st, xx, P, C, wsf);
+            hipLaunchKernelGGL(rowbn_stats_kernel<__hip_bfloat16>, dim3(G, nseg), dim3(BN_THREADS), 0, st, xx, P, C, wsf);
             hipLaunchKernelGGL(rowbn_stats_finalize_kernel<__hip_bfloat16>, fg, dim3(BN_THREADS), 0, st, xx, wsf, G, P,
-                               C, eps, momentum, running_mean, running_var, num_batches_tracked, mean, rstd);
+                               C, eps, momentum, running_mean, running_var, num_batches_tracked, mean_shift, mean, rstd, nseg);
         } else {
             const float *xx = static_cast<const float *>(x);
-            hipLaunchKernelGGL(rowbn_stats_kernel<float>, dim3(G), dim3(BN_THREADS), 0, st, xx, P, C, wsf);
+            hipLaunchKernelGGL(rowbn_stats_kernel<float>, dim3(G, nseg), dim3(BN_THREADS), 0, st, xx, P, C, wsf);
             hipLaunchKernelGGL(rowbn_stats_finalize_kernel<float>, fg, dim3(BN_THREADS), 0, st, xx, wsf, G, P, C, eps,
-                               momentum, running_mean, running_var, num_batches_tracked, mean, rstd);
+                               momentum, running_mean, running_var, num_batches_tracked, mean_shift, mean, rstd, nseg);
         }
     }  // eval mode: the caller has filled mean / rstd from the running statistics
     if (phase == TPG_BN_PHASE_STATS) {
@@ -702,8 +763,10 @@ extern "C" int tpg_rowbn_fwd(const void *x, int dtype_in, long long P, int K, in
     const int ne = (dtype_in == TPG_DTYPE_BF16 || dtype_out == TPG_DTYPE_BF16) ? 8 : 4;
     const int rpi_a = BN_THREADS / (C / ne);
     const long long rows_out = K > 0 ? P / K : P;
-    const dim3 g(K > 0 ? row_blocks(rows_out, rpi_a, 1, TPG_BN_GROUP_CAP)
-                       : row_blocks(P, rpi_a, TPG_BN_APPLY_ROWS, TPG_BN_APPLY_CAP));
+    // several segments share the chip: fewer workgroups per segment
+    const int cap_div = nseg > 4 ? 4 : nseg;
+    const dim3 g(K > 0 ? row_blocks(rows_out, rpi_a, 1, TPG_BN_GROUP_CAP / cap_div)
+                       : row_blocks(P, rpi_a, TPG_BN_APPLY_ROWS, TPG_BN_APPLY_CAP / cap_div), nseg);
     const dim3 blk(BN_THREADS);
     const int gu = group_unroll(K);
 #define TPG_BN_APPLY_MAX(TI, TO, U)                                                                       \
@@ -732,9 +795,11 @@ extern "C" int tpg_rowbn_fwd(const void *x, int dtype_in, long long P, int K, in
 extern "C" int tpg_rowbn_bwd(const void *gy, int dtype_g, const void *x, int dtype_in, const uint8_t *argmax,
                              const void *y, int dtype_y, long long P, int K, int C, int training,
                              const float *mean, const float *rstd, const float *gamma, const float *beta,
-                             float slope, float *dgamma, float *dbeta, void *dx, void *ws, int phase,
+                             float slope, float *dgamma, float *dbeta, void *dx, void *ws, int nseg, int phase,
                              void *stream) {
-    if (P <= 0 || C <= 0 || K < 0 || K > 256 || (K > 0 && P % K)) return TPG_ERR_ARG;
+    if (P <= 0 || C <= 0 || K < 0 || K > 256 || nseg < 1 || nseg > 65535 || P % nseg) return TPG_ERR_ARG;
+    P /= nseg;                                    // rows per segment from here on
+    if (K > 0 && P % K) return TPG_ERR_ARG;
     if (!gy || !x || !dx || !ws || (K > 0 && !argmax)) return TPG_ERR_ARG;
     if ((mean == nullptr) != (rstd == nullptr) || (training && !mean)) return TPG_ERR_ARG;
     if (!bn_dtype_ok(dtype_in) || !bn_dtype_ok(dtype_g) || !bn_shape_ok(dtype_in, dtype_g, C))
@@ -746,12 +811,14 @@ extern "C" int tpg_rowbn_bwd(const void *gy, int dtype_g, const void *x, int dty
     if (!(K > 0 && y && dtype_y == dtype_g && !(reinterpret_cast<uintptr_t>(y) & 15))) y = nullptr;
     hipStream_t st = tpg_stream(stream);
     float *wsf = static_cast<float *>(ws);
-    float *c12 = wsf + WS_HEAD + (size_t)BN_MAX_BLOCKS * 2 * C;
+    float *c12 = wsf + WS_HEAD + (size_t)nseg * BN_MAX_BLOCKS * 2 * C;      // (nseg, 2, C)
     const int ne = (dtype_in == TPG_DTYPE_BF16 || dtype_g == TPG_DTYPE_BF16) ? 8 : 4;
     const int rpi = BN_THREADS / (C / ne);
     const long long rows_g = K > 0 ? P / K : P;
-    const int G = K > 0 ? row_blocks(rows_g, rpi, TPG_BN_YRED_ROWS, BN_MAX_BLOCKS) : stats_blocks(rows_g, rpi);
-    const int GA = K > 0 ? row_blocks(rows_g, rpi, 1, TPG_BN_GROUP_CAP) : row_blocks(P, rpi, TPG_BN_APPLY_ROWS, TPG_BN_APPLY_CAP);
+    const int G = seg_blocks(K > 0 ? row_blocks(rows_g, rpi, TPG_BN_YRED_ROWS, BN_MAX_BLOCKS) : stats_blocks(rows_g, rpi), nseg);
+    const int cap_div = nseg > 4 ? 4 : nseg;
+    const int GA = K > 0 ? row_blocks(rows_g, rpi, 1, TPG_BN_GROUP_CAP / cap_div)
+                         : row_blocks(P, rpi, TPG_BN_APPLY_ROWS, TPG_BN_APPLY_CAP / cap_div);
     // no batch statistics and no affine gradients wanted (pure activation [+max]): dx = a * g,
     // nothing to reduce
     const bool wanted = training || dgamma || dbeta;
@@ -760,7 +827,7 @@ extern "C" int tpg_rowbn_bwd(const void *gy, int dtype_g, const void *x, int dty
     const float *c12_arg = wanted ? c12 : nullptr;     // absent constants read as zero
     const int gu = group_unroll(K);
 #define TPG_BN_BWD_APPLY_MAX(TI, TG, U)                                                                     \
-    hipLaunchKernelGGL((rowbn_bwd_apply_max_kernel<TI, TG, U>), dim3(GA), dim3(BN_THREADS), 0, st, gg, xx, argmax, \
+    hipLaunchKernelGGL((rowbn_bwd_apply_max_kernel<TI, TG, U>), dim3(GA, nseg), dim3(BN_THREADS), 0, st, gg, xx, argmax, \
                        rows_g, K, C, mean, rstd, gamma, beta, slope, c12_arg, static_cast<TI *>(dx))
 #define TPG_BN_BWD(TI, TG)                                                                                  \
     do {                                                                                                    \
@@ -768,22 +835,22 @@ extern "C" int tpg_rowbn_bwd(const void *gy, int dtype_g, const void *x, int dty
         const TG *gg = static_cast<const TG *>(gy);                                                         \
         if (!need_reduce) {                                                                                 \
         } else if (K > 0)                                                                                   \
-            hipLaunchKernelGGL((rowbn_bwd_reduce_max_kernel<TI, TG>), dim3(G), dim3(BN_THREADS), 0, st, gg, \
+            hipLaunchKernelGGL((rowbn_bwd_reduce_max_kernel<TI, TG>), dim3(G, nseg), dim3(BN_THREADS), 0, st, gg, \
                                static_cast<const TG *>(y), xx, argmax, rows_g, K, C, mean, rstd, gamma, beta, \
                                slope, wsf);                                                                 \
         else                                                                                                \
-            hipLaunchKernelGGL((rowbn_bwd_reduce_kernel<TI, TG>), dim3(G), dim3(BN_THREADS), 0, st, gg, xx, P, C, \
+            hipLaunchKernelGGL((rowbn_bwd_reduce_kernel<TI, TG>), dim3(G, nseg), dim3(BN_THREADS), 0, st, gg, xx, P, C, \
                                mean, rstd, gamma, beta, slope, wsf);                                        \
         if (need_reduce)                                                                                    \
             hipLaunchKernelGGL(rowbn_bwd_finalize_kernel, dim3((C + FIN_CH - 1) / FIN_CH), dim3(BN_THREADS), 0, st, \
-                               wsf, G, P, C, training, dgamma, dbeta, c12);                                 \
+                               wsf, G, P, C, training, dgamma, dbeta, c12, nseg);                           \
         if (!do_apply) {                                                                                    \
         } else if (K > 0) {                                                                                 \
             if (gu == 4) TPG_BN_BWD_APPLY_MAX(TI, TG, 4);                                                   \
             else if (gu == 2) TPG_BN_BWD_APPLY_MAX(TI, TG, 2);                                              \
             else TPG_BN_BWD_APPLY_MAX(TI, TG, 1);                                                           \
         } else                                                                                              \
-            hipLaunchKernelGGL((rowbn_bwd_apply_kernel<TI, TG>), dim3(GA), dim3(BN_THREADS), 0, st, gg, xx, P, C, \
+            hipLaunchKernelGGL((rowbn_bwd_apply_kernel<TI, TG>), dim3(GA, nseg), dim3(BN_THREADS), 0, st, gg, xx, P, C, \
                                mean, rstd, gamma, beta, slope, c12_arg, static_cast<TI *>(dx));            \
     } while (0)
     if (dtype_in == TPG_DTYPE_F32 && dtype_g == TPG_DTYPE_F32) TPG_BN_BWD(float, float);

@@ -167,6 +167,54 @@ def _mm_f32(fn, a, b):
     return fn(a, b, out_dtype=torch.float32) if _F32_OUT[0] else fn(a, b).float()
 
 
+class _TallLinearSeg(torch.autograd.Function):
+    """nseg independent tall products in one batched GEMM: rows x (nseg*P, Cin) are nseg equal
+    consecutive blocks, block s is multiplied by its own weight w[s] (Cout, Cin) -- the same
+    module called nseg times (T frames, fake / real batch) with the successive spectrally
+    normalised weights of those calls.  No bias: the caller folds it into the BatchNorm that
+    follows (ops.row_bn_act, mean_shift).  Weight gradients per block by split-K like _TallLinear."""
+
+    @staticmethod
+    def forward(ctx, x, w, dtype):
+        nseg, cout, cin = w.shape
+        P = x.shape[0] // nseg
+        xd = x.to(dtype).view(nseg, P, cin)
+        wd = w.to(dtype)
+        ctx.save_for_backward(xd, wd)
+        ctx.w_dtype, ctx.x_dtype = w.dtype, x.dtype
+        return torch.bmm(xd, wd.transpose(1, 2)).view(nseg * P, cout)
+
+    @staticmethod
+    def backward(ctx, gy):
+        xd, wd = ctx.saved_tensors
+        nseg, P, cin = xd.shape
+        cout = wd.shape[1]
+        gy = gy.to(xd.dtype).view(nseg, P, cout)
+        dx = dw = None
+        if ctx.needs_input_grad[0]:
+            dx = torch.bmm(gy, wd).view(nseg * P, cin).to(ctx.x_dtype)
+        if ctx.needs_input_grad[1]:
+            S = _split_k(P, cout, cin)
+            rows = P // S
+            head = S * rows
+            part = _mm_f32(torch.bmm, gy[:, :head].reshape(nseg * S, rows, cout).transpose(1, 2),
+                           xd[:, :head].reshape(nseg * S, rows, cin))
+            dw = part.view(nseg, S, cout, cin).sum(1) if S > 1 else part.view(nseg, cout, cin)
+            if head < P:
+                dw = dw + _mm_f32(torch.bmm, gy[:, head:].transpose(1, 2), xd[:, head:])
+            dw = dw.to(ctx.w_dtype)
+        return dx, dw, None
+
+
+def rows_matmul_seg(x, w):
+    """x (nseg*P, Cin) rows in nseg equal blocks, w (nseg, Cout, Cin): block s times w[s]^T."""
+    dtype = torch.get_autocast_gpu_dtype() if (x.is_cuda and torch.is_autocast_enabled()) else x.dtype
+    if dtype not in (torch.float32, torch.bfloat16, torch.float16):
+        dtype = torch.float32
+    with torch.autocast(device_type=x.device.type, enabled=False):
+        return _TallLinearSeg.apply(x, w, dtype)
+
+
 def _split_k(P, cout, cin):
     """Slices of the row axis for the weight-gradient GEMM: aim at >= 512 workgroups of 64x64
     output tiles, keep >= 1024 rows per slice."""

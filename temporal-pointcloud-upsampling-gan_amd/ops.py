@@ -259,28 +259,29 @@ class HipBackend:
 
 
     # ---- fused BatchNorm + LeakyReLU (+ max over K) on rows (csrc/rowbn.hip) -------------
-    def _bn_ws(self, x, C_):
+    def _bn_ws(self, x, C_, nseg=1):
         # one scratch buffer per (device, stream), reused by every call: launches on a stream are
         # ordered, so the next call cannot start before the previous one has consumed it
         key = (x.device, torch.cuda.current_stream(x.device).cuda_stream)
         ws = self._ws.get(key)
-        need = self.lib.tpg_rowbn_workspace_bytes(max(C_, 256)) // 4
+        need = self.lib.tpg_rowbn_workspace_bytes(max(C_, 256), max(nseg, 1)) // 4
         if ws is None or ws.numel() < need:
             ws = torch.zeros(need, dtype=torch.float32, device=x.device)
             self._ws[key] = ws
         return ws
 
     def rowbn_fwd(self, x, K, eps, momentum, training, running_mean, running_var, gamma, beta, slope,
-                  mean, rstd, out_dtype, num_batches_tracked=None):
+                  mean, rstd, out_dtype, num_batches_tracked=None, nseg=1, mean_shift=None):
         P, Cc = x.shape
         rows = P // K if K else P
         y = torch.empty((rows, Cc), dtype=out_dtype, device=x.device)
         arg = torch.empty((rows, Cc), dtype=torch.uint8, device=x.device) if K else None
-        ws = self._bn_ws(x, Cc)
+        ws = self._bn_ws(x, Cc, nseg)
         args = (_ptr(x), _DTYPE_CODE[x.dtype], P, K, Cc, float(eps), float(momentum), int(training),
-                _ptr(running_mean), _ptr(running_var), _ptr(num_batches_tracked), _ptr(gamma), _ptr(beta),
+                _ptr(running_mean), _ptr(running_var), _ptr(num_batches_tracked), _ptr(mean_shift), _ptr(gamma),
+                _ptr(beta),
                 float(slope), _ptr(mean),
-                _ptr(rstd), _ptr(y), _DTYPE_CODE[out_dtype], _ptr(arg), _ptr(ws))
+                _ptr(rstd), _ptr(y), _DTYPE_CODE[out_dtype], _ptr(arg), _ptr(ws), int(nseg))
         b_stats = x.element_size() * P * Cc
         b_apply = x.element_size() * P * Cc + y.element_size() * rows * Cc + (rows * Cc if K else 0)
         if _timer is None:
@@ -291,18 +292,18 @@ class HipBackend:
             self._call("tpg_rowbn_fwd", "rowbn_fwd_apply_max" if K else "rowbn_fwd_apply", b_apply, x, *args, 2)
         return y, arg
 
-    def rowbn_bwd(self, gy, x, arg, K, training, mean, rstd, gamma, beta, slope, need_affine, y=None):
+    def rowbn_bwd(self, gy, x, arg, K, training, mean, rstd, gamma, beta, slope, need_affine, y=None, nseg=1):
         P, Cc = x.shape
         dx = torch.empty_like(x)
         dgamma = torch.empty(Cc, dtype=torch.float32, device=x.device) if need_affine else None
         dbeta = torch.empty(Cc, dtype=torch.float32, device=x.device) if need_affine else None
-        ws = self._bn_ws(x, Cc)
+        ws = self._bn_ws(x, Cc, nseg)
         if y is not None and (not K or y.dtype != gy.dtype):
             y = None
         args = (_ptr(gy), _DTYPE_CODE[gy.dtype], _ptr(x), _DTYPE_CODE[x.dtype], _ptr(arg), _ptr(y),
                 _DTYPE_CODE[y.dtype] if y is not None else 0, P, K, Cc,
                 int(training), _ptr(mean), _ptr(rstd), _ptr(gamma), _ptr(beta), float(slope), _ptr(dgamma),
-                _ptr(dbeta), _ptr(dx), _ptr(ws))
+                _ptr(dbeta), _ptr(dx), _ptr(ws), int(nseg))
         b_gy = gy.element_size() * gy.numel() + (gy.numel() if K else 0)
         b_reduce = (2 * gy.element_size() * gy.numel() if y is not None
                     else b_gy + x.element_size() * (gy.numel() if K else P * Cc))
@@ -671,48 +672,60 @@ def attach_inverse(idx, N):
 class _RowBNAct(torch.autograd.Function):
     @staticmethod
     def forward(ctx, x, gamma, beta, running_mean, running_var, training, momentum, eps, slope, K, out_dtype,
-                num_batches_tracked):
+                num_batches_tracked, nseg, mean_shift):
         be = backend_for(x)
         C_ = x.shape[1]
         if training:
-            mean = torch.empty(C_, dtype=torch.float32, device=x.device)
-            rstd = torch.empty(C_, dtype=torch.float32, device=x.device)
+            mean = torch.empty((nseg, C_), dtype=torch.float32, device=x.device)
+            rstd = torch.empty((nseg, C_), dtype=torch.float32, device=x.device)
         elif running_mean is None:                  # identity statistics: activation (+max) only
             mean = rstd = None
         else:
             mean = running_mean.float().contiguous()
+            if mean_shift is not None:
+                mean = mean - mean_shift.float()
             rstd = torch.rsqrt(running_var.float() + eps)
         y, arg = be.rowbn_fwd(x, K, eps, momentum, training, running_mean if training else None,
                               running_var if training else None, gamma, beta, slope, mean, rstd, out_dtype,
-                              num_batches_tracked if training else None)
+                              num_batches_tracked if training else None, **({"nseg": nseg} if nseg != 1 else {}),
+                              **({"mean_shift": mean_shift} if mean_shift is not None and training else {}))
         # K > 0: the (small) output doubles as the backward's source of the arg-max pre-activations
         ctx.save_for_backward(x, gamma, beta, mean, rstd, arg, y if K else None)
-        ctx.cfg = (training, slope, K)
+        ctx.cfg = (training, slope, K, nseg)
         return y
 
     @staticmethod
     def backward(ctx, gy):
         x, gamma, beta, mean, rstd, arg, y = ctx.saved_tensors
-        training, slope, K = ctx.cfg
+        training, slope, K, nseg = ctx.cfg
         gy = gy.contiguous()
         if gy.dtype not in _DTYPE_CODE:
             gy = gy.float()
         need_affine = gamma is not None and (ctx.needs_input_grad[1] or ctx.needs_input_grad[2])
         dx, dgamma, dbeta = backend_for(x).rowbn_bwd(gy, x, arg, K, training, mean, rstd, gamma, beta, slope,
-                                                    need_affine, y)
-        return dx, dgamma, dbeta, None, None, None, None, None, None, None, None, None
+                                                    need_affine, y, **({"nseg": nseg} if nseg != 1 else {}))
+        return dx, dgamma, dbeta, None, None, None, None, None, None, None, None, None, None, None
 
 
 def row_bn_act(x, gamma, beta, running_mean, running_var, training, momentum, eps, slope=1.0, K=0,
-               out_dtype=None, num_batches_tracked=None):
+               out_dtype=None, num_batches_tracked=None, nseg=1, mean_shift=None):
     """Fused BatchNorm (+LeakyReLU, + max over groups of K rows) on rows (include/tpgan_ops.h).
 
     x (P,C) fp32/bf16 -> (P,C) or (P/K,C).  slope: 1.0 = no activation, 0.0 = ReLU.  In training mode
     the running statistics are updated in place (momentum, unbiased variance) like nn.BatchNorm,
     and `num_batches_tracked` (int64 scalar tensor, optional) is incremented by the same launch.
-    Eval mode with running_mean = running_var = None means identity statistics."""
+    Eval mode with running_mean = running_var = None means identity statistics.
+    nseg > 1 (training): the rows are nseg equal consecutive blocks, each normalised with its own
+    batch statistics -- nseg calls of the same module in one launch, running statistics updated
+    block after block (see include/tpgan_ops.h).
+    mean_shift (C) fp32, no gradient: a per-channel constant (the preceding conv's bias) that was
+    left out of x; only the running mean needs it (BatchNorm(x + b) == BatchNorm(x))."""
     _need(x.dim() == 2 and x.dtype in _DTYPE_CODE, "x must be (P,C) fp32/bf16")
     _need(K == 0 or (0 < K <= 256 and x.shape[0] % K == 0), "K must divide the row count (<= 256)")
+    _need(nseg >= 1 and x.shape[0] % nseg == 0 and (K == 0 or (x.shape[0] // nseg) % K == 0),
+          "nseg must divide the rows (and K the rows of a segment)")
+    if not training:
+        nseg = 1                                      # fixed statistics: segments are meaningless
     out_dtype = out_dtype or x.dtype
     ne = 4 if (x.dtype == torch.float32 and out_dtype == torch.float32) else 8
     _need(x.shape[1] % ne == 0 and x.shape[1] <= 1024, f"channels must be a multiple of {ne}, <= 1024")
@@ -724,7 +737,8 @@ def row_bn_act(x, gamma, beta, running_mean, running_var, training, momentum, ep
     g = None if gamma is None else gamma.float().contiguous()
     b = None if beta is None else beta.float().contiguous()
     return _RowBNAct.apply(x.contiguous(), g, b, running_mean, running_var, bool(training), float(momentum),
-                           float(eps), float(slope), int(K), out_dtype, num_batches_tracked)
+                           float(eps), float(slope), int(K), out_dtype, num_batches_tracked, int(nseg),
+                           None if mean_shift is None else mean_shift.detach().float().contiguous())
 
 
 def row_act_max(x, slope, K, out_dtype=None):

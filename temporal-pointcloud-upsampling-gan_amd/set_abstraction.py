@@ -29,7 +29,7 @@ import torch.nn.functional as F
 from torch.nn.utils import spectral_norm
 
 from . import ops
-from .graph_conv import amp_dtype, no_autocast, reference_order, rows_first, rows_matmul  # noqa: F401
+from .graph_conv import amp_dtype, no_autocast, reference_order, rows_first, rows_matmul, rows_matmul_seg  # noqa: F401
 
 
 def knn(k, xyz1, xyz2):
@@ -144,14 +144,17 @@ def _fusable(x, K):
     return x.dtype in (torch.float32, torch.bfloat16) and C % 8 == 0 and C <= 1024 and K <= 256
 
 
-def bn_act_rows(bn, x, slope, K=0):
+def bn_act_rows(bn, x, slope, K=0, nseg=1, mean_shift=None):
     """Fused BatchNorm + LeakyReLU(slope) [+ max over each group of K rows] on rows (P,C)
-    (ops.row_bn_act, csrc/rowbn.hip); module state handled like nn.BatchNorm's own forward."""
+    (ops.row_bn_act, csrc/rowbn.hip); module state handled like nn.BatchNorm's own forward.
+    nseg > 1: the rows are nseg equal blocks = nseg successive calls of `bn` in one launch.
+    mean_shift: bias of the preceding conv that was left out of x (ops.row_bn_act)."""
     training = bn.training or (bn.running_mean is None and bn.running_var is None)
     momentum = 0.0 if bn.momentum is None else bn.momentum
     nbt = None
     if bn.training and bn.track_running_stats and bn.num_batches_tracked is not None:
         if bn.momentum is None:                    # cumulative average: the factor is needed on the host
+            assert nseg == 1, "segmented BatchNorm needs a fixed momentum"
             bn.num_batches_tracked.add_(1)
             momentum = 1.0 / float(bn.num_batches_tracked)
         else:
@@ -159,29 +162,71 @@ def bn_act_rows(bn, x, slope, K=0):
     track = bn.track_running_stats and bn.running_mean is not None
     return ops.row_bn_act(x, bn.weight, bn.bias, bn.running_mean if track else None,
                           bn.running_var if track else None, training, momentum, bn.eps, slope, K,
-                          out_dtype=amp_dtype(x), num_batches_tracked=nbt)
+                          out_dtype=amp_dtype(x), num_batches_tracked=nbt, nseg=nseg, mean_shift=mean_shift)
 
 
-def mlp_tail_rows(layers, x, reduce_max=False):
+def conv_weights_seg(conv, nseg):
+    """(nseg, Cout, Cin): the weights of `nseg` successive calls of a 1x1 conv (one power
+    iteration each when it is spectrally normalised)."""
+    if not hasattr(conv, "weight_orig"):
+        w = conv.weight
+        return w.view(1, w.shape[0], -1).expand(nseg, -1, -1)
+    return torch.stack([conv_weight2d(conv) for _ in range(nseg)])
+
+
+def _segmentable(layers, x, K):
+    """Can `nseg` calls of this tail run as ONE segmented pass?  Every conv must be followed by a
+    BatchNorm + (Leaky)ReLU pair the fused kernel takes (training-mode statistics, fixed
+    momentum), and the rows must be on the GPU."""
+    if not (x.is_cuda and rows_first()):
+        return False
+    n = len(layers)
+    for i, m in enumerate(layers):
+        if isinstance(m, nn.Conv2d):
+            if not (i + 2 < n and isinstance(layers[i + 1], nn.BatchNorm2d)):
+                return False
+            if m.out_channels % 8 or m.out_channels > 1024:
+                return False
+        elif isinstance(m, (nn.BatchNorm2d, nn.BatchNorm1d)):
+            if not (m.training and m.momentum is not None and i + 1 < n and _act_slope(layers[i + 1]) is not None):
+                return False
+        elif _act_slope(m) is None:
+            return False
+    return K <= 256 and x.shape[-1] % 8 == 0 and x.shape[-1] <= 1024
+
+
+def mlp_tail_rows(layers, x, reduce_max=False, nseg=1):
     """Run [conv, (bn), act]* layers (from a given position) on rows x (...,K,C).
 
     BatchNorm + activation pairs go through the fused kernel; with `reduce_max` the max over
-    the second-to-last axis (the K neighbours) is fused into the final pair."""
+    the second-to-last axis (the K neighbours) is fused into the final pair.
+    nseg > 1: the leading axis holds nseg equal blocks (frames, fake / real batch) that the
+    reference pushes through this tail one call after the other; here they share every launch --
+    one batched GEMM with the nseg successive weights, one segmented BatchNorm pass -- with the
+    statistics, running statistics and spectral-norm iterations of the separate calls."""
     lead, K = x.shape[:-2], x.shape[-2]
+    if nseg > 1 and not _segmentable(layers, x, K):
+        outs = [mlp_tail_rows(layers, xs, reduce_max) for xs in x.chunk(nseg, 0)]
+        return torch.cat(outs, 0)
     x = x.reshape(-1, x.shape[-1])
-    i, n, reduced = 0, len(layers), False
+    i, n, reduced, shift = 0, len(layers), False, None
     while i < n:
         m = layers[i]
-        if isinstance(m, nn.Conv2d):
+        if isinstance(m, nn.Conv2d) and nseg > 1:
+            x = rows_matmul_seg(x, conv_weights_seg(m, nseg))      # bias: folded into the next BN
+            shift = m.bias
+        elif isinstance(m, nn.Conv2d):
             x = rows_matmul(x, conv_weight2d(m), m.bias)
         elif isinstance(m, (nn.BatchNorm2d, nn.BatchNorm1d)):
             slope = _act_slope(layers[i + 1]) if i + 1 < n else None
             last = reduce_max and not any(isinstance(l, nn.Conv2d) for l in layers[i + 1:])
             if slope is not None and _fusable(x, K if last else 0):
-                x = bn_act_rows(m, x, slope, K if last else 0)
+                x = bn_act_rows(m, x, slope, K if last else 0, nseg=nseg, mean_shift=shift)
+                shift = None
                 reduced = reduced or last
                 i += 1                                             # the activation is consumed
             else:
+                assert nseg == 1
                 x = bn_rows(m, x)
         else:
             x = m(x)
@@ -354,8 +399,10 @@ class _PointnetSAModuleBase(nn.Module):
                 Qs.append(rows_matmul(new_xyz[sl], W[:, :3]))
         y = ops.row_combine(torch.cat(Us, 0), torch.cat(Qs, 0), idx, ops.ROW_SUB, out_dtype=amp_dtype(xyz))
         tail = list(mlp)[1:]
-        # unbind, not T slices: its backward is ONE stack instead of T x (zero-fill + copy + add)
-        feats = [mlp_tail_rows(tail, yt, reduce_max=True) for yt in y.view(T, B, *y.shape[1:]).unbind(0)]
+        # the T frames are T segments of ONE pass through the tail (per-frame statistics and
+        # spectral-norm iterations inside); unbind, not T slices: its backward is one stack
+        feats = mlp_tail_rows(tail, y, reduce_max=True, nseg=T)                 # (T*B, S, C')
+        feats = list(feats.view(T, B, *feats.shape[1:]).unbind(0))
         return [new_xyz[t * B:(t + 1) * B] for t in range(T)], feats
 
     def forward(self, xyz, features):

@@ -1,0 +1,86 @@
+"""Segmented launches (nseg calls of one module in one pass) against the separate calls they stand for."""
+import copy
+
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.mark.parametrize("K", [0, 16])
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+def test_row_bn_act_segments_equal_separate_calls(K, dtype):
+    import tpgan_amd.ops as ops
+    torch.manual_seed(0)
+    nseg, Ps, C = 3, 2 * 64 * 16, 64
+    x = (torch.randn(nseg * Ps, C, device="cuda") * 1.5 + torch.arange(nseg, device="cuda").repeat_interleave(Ps)[:, None]).to(dtype)
+    gamma = (torch.rand(C, device="cuda") + 0.5).requires_grad_(True)
+    beta = (torch.randn(C, device="cuda") * 0.1).requires_grad_(True)
+    shift = torch.randn(C, device="cuda")
+    rows = nseg * Ps // K if K else nseg * Ps
+    gy = torch.randn(rows, C, device="cuda").to(dtype)
+
+    def run(segmented):
+        rm, rv = torch.zeros(C, device="cuda"), torch.ones(C, device="cuda")
+        nbt = torch.zeros((), dtype=torch.int64, device="cuda")
+        xx = x.clone().requires_grad_(True)
+        g, b = gamma.detach().clone().requires_grad_(True), beta.detach().clone().requires_grad_(True)
+        if segmented:
+            y = ops.row_bn_act(xx, g, b, rm, rv, True, 0.1, 1e-5, 0.2, K, num_batches_tracked=nbt, nseg=nseg,
+                               mean_shift=shift)
+        else:
+            y = torch.cat([ops.row_bn_act(xs, g, b, rm, rv, True, 0.1, 1e-5, 0.2, K, num_batches_tracked=nbt,
+                                          mean_shift=shift) for xs in xx.chunk(nseg, 0)], 0)
+        y.backward(gy)
+        return y.detach(), xx.grad, g.grad, b.grad, rm, rv, int(nbt)
+
+    a, b = run(True), run(False)
+    assert a[6] == b[6] == nseg
+    # same per-segment math; the segmented launch splits the rows over fewer workgroups per
+    # segment, so the fp32 partial sums of the statistics associate differently (last-bit)
+    tol = 1e-5 if dtype == torch.float32 else 1.6e-2                    # bf16: one rounding step
+    assert torch.allclose(a[0].float(), b[0].float(), rtol=tol, atol=tol)
+    assert torch.allclose(a[1].float(), b[1].float(), rtol=tol, atol=tol * float(b[1].float().abs().max()))
+    assert torch.allclose(a[4], b[4], rtol=1e-5, atol=1e-6) and torch.allclose(a[5], b[5], rtol=1e-5, atol=1e-6)
+    for u, v in zip(a[2:4], b[2:4]):                                    # dgamma / dbeta: fp64 sum vs fp32 adds
+        assert torch.allclose(u, v, rtol=1e-5, atol=1e-4 * float(v.abs().max()))
+    # the shift reaches the running mean only
+    rm0 = torch.zeros(C, device="cuda")
+    for sg in range(nseg):
+        rm0 = 0.9 * rm0 + 0.1 * (x[sg * Ps:(sg + 1) * Ps].float().mean(0) + shift)
+    assert torch.allclose(a[4], rm0, atol=2e-3 if dtype == torch.bfloat16 else 1e-5)
+
+
+def test_segmented_tail_equals_per_frame_calls():
+    """T frames through a set-abstraction level as T segments == T separate forward_rows calls:
+    features, BatchNorm running statistics, spectral-norm vectors and parameter gradients."""
+    from tpgan_amd.set_abstraction import SSGSetConv
+    torch.manual_seed(1)
+    T, B, N = 3, 2, 512
+    sa_a = SSGSetConv(npoint=128, radius=0.2, nsample=16, mlp=[3, 32, 32, 64], use_xyz=True, sn=True).cuda().train()
+    sa_b = copy.deepcopy(sa_a)
+    xyz = [torch.rand(B, N, 3, device="cuda") for _ in range(T)]
+    feat = [x.clone().requires_grad_(True) for x in xyz]
+    feat_b = [x.clone().requires_grad_(True) for x in xyz]
+    pos_a, out_a = sa_a.forward_rows_frames(xyz, feat)                       # segmented tail
+    outs_b = [sa_b.forward_rows(x, f) for x, f in zip(xyz, feat_b)]          # the reference's call pattern
+    g = [torch.randn_like(o) for o in out_a]
+    torch.autograd.backward(out_a, g)
+    torch.autograd.backward([o[1] for o in outs_b], g)
+    for t in range(T):
+        assert torch.equal(pos_a[t], outs_b[t][0])
+        assert torch.allclose(out_a[t], outs_b[t][1], rtol=1e-4, atol=1e-5)
+        assert torch.allclose(feat[t].grad, feat_b[t].grad, rtol=1e-3, atol=1e-5 * float(feat_b[t].grad.abs().max() + 1))
+    sd_a, sd_b = sa_a.state_dict(), sa_b.state_dict()
+    for k in sd_a:
+        assert torch.allclose(sd_a[k].float(), sd_b[k].float(), rtol=1e-5, atol=1e-6), k
+    for (n, pa), (_, pb) in zip(sa_a.named_parameters(), sa_b.named_parameters()):
+        if pb.grad is None:
+            assert pa.grad is None, n
+            continue
+        if pa.grad is None:      # conv biases ahead of a BatchNorm: analytically zero gradient, folded away
+            assert n.endswith("bias") and float(pb.grad.abs().max()) <= 1e-3 * float(g[0].abs().max()) * 64, n
+            continue
+        ref = float(pb.grad.abs().max()) + 1e-12
+        assert float((pa.grad - pb.grad).abs().max()) <= 2e-3 * ref, n

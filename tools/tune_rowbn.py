@@ -71,23 +71,23 @@ def run(reps):
         for tag in VARIANTS:
             lib = C.CDLL(os.path.join(VDIR, f"rowbn_{tag}.so"))
             lib.tpg_rowbn_workspace_bytes.restype = C.c_size_t
-            lib.tpg_rowbn_workspace_bytes.argtypes = [I]
-            ws = torch.zeros(lib.tpg_rowbn_workspace_bytes(Cc), dtype=torch.uint8, device=dev)
-            lib.tpg_rowbn_fwd.argtypes = [P_, I, L, I, I, F, F, I, P_, P_, P_, P_, P_, F, P_, P_, P_, I, P_, P_, I, P_]
-            lib.tpg_rowbn_bwd.argtypes = [P_, I, P_, I, P_, P_, I, L, I, I, I, P_, P_, P_, P_, F, P_, P_, P_, P_, I, P_]
+            lib.tpg_rowbn_workspace_bytes.argtypes = [I, I]
+            ws = torch.zeros(lib.tpg_rowbn_workspace_bytes(Cc, 1), dtype=torch.uint8, device=dev)
+            lib.tpg_rowbn_fwd.argtypes = [P_, I, L, I, I, F, F, I, P_, P_, P_, P_, P_, P_, F, P_, P_, P_, I, P_, P_, I, I, P_]
+            lib.tpg_rowbn_bwd.argtypes = [P_, I, P_, I, P_, P_, I, L, I, I, I, P_, P_, P_, P_, F, P_, P_, P_, P_, I, I, P_]
 
             def fwd(s, phase, st=st):
-                rc = lib.tpg_rowbn_fwd(s["x"].data_ptr(), 1, P, K, Cc, 1e-5, 0.1, 1, None, None, None,
+                rc = lib.tpg_rowbn_fwd(s["x"].data_ptr(), 1, P, K, Cc, 1e-5, 0.1, 1, None, None, None, None,
                                        gamma.data_ptr(), beta.data_ptr(), 0.2, mean.data_ptr(), rstd.data_ptr(),
                                        s["y"].data_ptr(), 1, s["arg"].data_ptr() if K else None, ws.data_ptr(),
-                                       phase, st)
+                                       1, phase, st)
                 assert rc == 0, rc
 
             def bwd(s, phase, st=st):
                 rc = lib.tpg_rowbn_bwd(s["gy"].data_ptr(), 1, s["x"].data_ptr(), 1, s["arg"].data_ptr() if K else None,
                                        s["y"].data_ptr() if K else None, 1, P, K, Cc, 1, mean.data_ptr(),
                                        rstd.data_ptr(), gamma.data_ptr(), beta.data_ptr(), 0.2, dg.data_ptr(),
-                                       db.data_ptr(), s["dx"].data_ptr(), ws.data_ptr(), phase, st)
+                                       db.data_ptr(), s["dx"].data_ptr(), ws.data_ptr(), 1, phase, st)
                 assert rc == 0, rc
 
             for s in sets:      # valid statistics / arg-max / y everywhere
