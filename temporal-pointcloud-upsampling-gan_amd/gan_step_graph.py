@@ -182,8 +182,10 @@ class GraphedFluidStep:
                     fake_s = torch.bmm(last_padded.detach().float(), self.rot_fake_s)
                     if not self.use_plans:
                         return fakes, fake_s, None, None
-                    return fakes, fake_s, Dt.index_plan(fakes, opt.R), Ds.index_plan(fake_s)
-                (k["fakes"], k["fake_s"], k["plan_fake_t"], k["plan_fake_s"]), k["join_fake"] = \
+                    # fake and real batch run as segments of ONE discriminator pass: one plan for both
+                    return (fakes, fake_s, Dt.merge_plans([Dt.index_plan(fakes, opt.R), k["plan_true_t"]]),
+                            Ds.merge_plans([Ds.index_plan(fake_s), k["plan_true_s"]]))
+                (k["fakes"], k["fake_s"], k["plan_t"], k["plan_s"]), k["join_fake"] = \
                     run_index_plan(fake_side, self.side)
             join_fs()
             fake = Ds(fake_s_in, plan=plan_fs)
@@ -206,8 +208,7 @@ class GraphedFluidStep:
             k["tempo_dis_loss"] = torch.zeros((), device=self.dev)
             return
         with _autocast(self.amp, self.dev):
-            fake = self.Dt(k["fakes"], self.opt.R, plan=k["plan_fake_t"])
-            true = self.Dt(k["trues"], self.opt.R, plan=k["plan_true_t"])
+            fake, true = self.Dt.forward_passes([k["fakes"], k["trues"]], self.opt.R, plan=k["plan_t"])
         loss = (0.5 * ((true.float() - lab[0]) ** 2 + (fake.float() - lab[1]) ** 2)).mean()
         self.ot.zero_grad(set_to_none=True)
         loss.backward()
@@ -220,8 +221,7 @@ class GraphedFluidStep:
             return
         self.ot.step()
         with _autocast(self.amp, self.dev):
-            fake = self.Ds(k["fake_s"], plan=k["plan_fake_s"])
-            true = self.Ds(k["true_s"], plan=k["plan_true_s"])
+            fake, true = self.Ds.forward_passes([k["fake_s"], k["true_s"]], plan=k["plan_s"])
         loss = (0.5 * ((true.float() - lab[0]) ** 2 + (fake.float() - lab[1]) ** 2)).mean()
         self.os.zero_grad(set_to_none=True)
         loss.backward()

@@ -367,43 +367,72 @@ class _PointnetSAModuleBase(nn.Module):
                 outs.append(F.max_pool2d(g, kernel_size=[1, g.size(3)]).squeeze(-1).transpose(1, 2))
         return new_xyz, torch.cat(outs, dim=-1)
 
+    def frames_stackable(self):
+        single = len(self.groupers) == 1 and isinstance(self.groupers[0], QueryAndGroup)
+        return rows_first() and self.npoint is not None and single and self.groupers[0].use_xyz
+
     def forward_rows_frames(self, xyz_lst, feat_rows_lst, plan=None):
         """T frames of one clip through this level: lists of (B,N,3) / (B,N,C) -> lists.
 
         Exactly T separate `forward_rows` calls (per-frame spectral-norm power iterations,
-        per-frame BatchNorm statistics, same order of host RNG draws), except that the
+        per-frame BatchNorm statistics), except that the T calls share their launches: the
         index-only work -- FPS, centre gather, ball query, the row gather -- runs ONCE on the
-        T*B stacked clouds: those ops have no cross-cloud coupling, and FPS in particular is
-        a chain of npoint-1 dependent rounds whose latency is paid per launch, not per cloud."""
+        T*B stacked clouds (no cross-cloud coupling; FPS in particular is a chain of npoint-1
+        dependent rounds whose latency is paid per launch, not per cloud), and the MLP runs
+        as T segments of batched GEMMs / segmented BatchNorm passes (`forward_rows_stacked`)."""
         T = len(xyz_lst)
-        single = len(self.groupers) == 1 and isinstance(self.groupers[0], QueryAndGroup)
-        if T == 1 or not rows_first() or self.npoint is None or not single or not self.groupers[0].use_xyz:
+        if T == 1 or not self.frames_stackable():
             assert plan is None, "index plans need the stacked-frames path"
             outs = [self.forward_rows(x, f) for x, f in zip(xyz_lst, feat_rows_lst)]
             return [o[0] for o in outs], [o[1] for o in outs]
         B = xyz_lst[0].shape[0]
+        xyz = torch.cat([x.float() for x in xyz_lst], 0)
+        feat = None if feat_rows_lst[0] is None else torch.cat(list(feat_rows_lst), 0)
+        new_xyz, feats = self.forward_rows_stacked(xyz, feat, T, plan)
+        return list(new_xyz.view(T, B, *new_xyz.shape[1:]).unbind(0)), list(feats.view(T, B, *feats.shape[1:]).unbind(0))
+
+    def forward_rows_stacked(self, xyz, feat, nseg, plan=None):
+        """`nseg` calls of this level in one pass: xyz (nseg*B,N,3), feat (nseg*B,N,C)|None, the
+        calls stacked along the cloud axis in call order -> new_xyz (nseg*B,S,3), rows
+        (nseg*B,S,C').  plan = (centres, idx) of the stacked clouds (`index_level`)."""
+        assert self.frames_stackable()
         grouper, mlp = self.groupers[0], self.mlps[0]
-        xyz = torch.cat([x.float() for x in xyz_lst], 0).contiguous()
+        xyz = xyz.float().contiguous()
+        NB, N, _ = xyz.shape
         centres = plan[0] if plan is not None else self.sample_centres(xyz)
         new_xyz = ops.gather_operation(xyz.transpose(1, 2).contiguous(), centres).transpose(1, 2).contiguous()
         idx = plan[1] if plan is not None else ops.ball_query(grouper.radius, grouper.nsample, xyz, new_xyz)
+        S = new_xyz.shape[1]
         conv = mlp[0]
-        Us, Qs = [], []
+        rows_dtype = amp_dtype(xyz)
         with no_autocast(xyz):
-            for t in range(T):
-                W = conv_weight2d(conv).float()                    # one power iteration per frame
-                sl = slice(t * B, (t + 1) * B)
-                f = feat_rows_lst[t]
-                src = xyz[sl] if f is None else torch.cat([xyz[sl], f.float()], dim=-1)
-                Us.append(rows_matmul(src, W, conv.bias))
-                Qs.append(rows_matmul(new_xyz[sl], W[:, :3]))
-        y = ops.row_combine(torch.cat(Us, 0), torch.cat(Qs, 0), idx, ops.ROW_SUB, out_dtype=amp_dtype(xyz))
-        tail = list(mlp)[1:]
-        # the T frames are T segments of ONE pass through the tail (per-frame statistics and
-        # spectral-norm iterations inside); unbind, not T slices: its backward is one stack
-        feats = mlp_tail_rows(tail, y, reduce_max=True, nseg=T)                 # (T*B, S, C')
-        feats = list(feats.view(T, B, *feats.shape[1:]).unbind(0))
-        return [new_xyz[t * B:(t + 1) * B] for t in range(T)], feats
+            # first conv BEFORE the gather, per call with that call's weight: y = U[idx] - Q,
+            # U = W_s [xyz|feat] (all points), Q = W_s[:, :3] centre - bias (bias folded into Q)
+            W = conv_weights_seg(conv, nseg).float()                           # (nseg, C1, Cin)
+            src = xyz if feat is None else torch.cat([xyz, feat.float()], dim=-1)
+            U = rows_matmul_seg(src.view(NB * N, -1), W).view(NB, N, -1)
+            Q = rows_matmul_seg(new_xyz.view(NB * S, 3), W[:, :, :3].contiguous()).view(NB, S, -1)
+            if conv.bias is not None:
+                Q = Q - conv.bias.float()
+        y = ops.row_combine(U, Q, idx, ops.ROW_SUB, out_dtype=rows_dtype)        # (nseg*B, S, K, C1)
+        feats = mlp_tail_rows(list(mlp)[1:], y, reduce_max=True, nseg=nseg)     # (nseg*B, S, C')
+        return new_xyz, feats
+
+    def forward_rows_pool_stacked(self, xyz, feat, nseg):
+        """`nseg` calls of a GroupAll level (npoint None: one group holding all N points) in one
+        pass: xyz (nseg*B,N,3), feat (nseg*B,N,C) -> (nseg*B, C')."""
+        grouper, mlp = self.groupers[0], self.mlps[0]
+        assert self.npoint is None and isinstance(grouper, GroupAll) and len(self.groupers) == 1
+        NB, N, _ = xyz.shape
+        conv = mlp[0]
+        with no_autocast(xyz):
+            W = conv_weights_seg(conv, nseg).float()
+            src = torch.cat([xyz.float(), feat.float()], dim=-1) if grouper.use_xyz else feat.float()
+            y = rows_matmul_seg(src.reshape(NB * N, -1), W)
+            if conv.bias is not None:
+                y = y + conv.bias.float()
+        y = y.view(NB, 1, N, -1)                                                   # one group of N rows per cloud
+        return mlp_tail_rows(list(mlp)[1:], y, reduce_max=True, nseg=nseg).view(NB, -1)
 
     def forward(self, xyz, features):
         """Reference signature: xyz (B,N,3), features (B,C,N) -> new_xyz, (B,C',npoint)."""
@@ -495,6 +524,27 @@ class FlowEmbedding(nn.Module):
                     x = x.view(B * N, K, -1).max(dim=1)[0]
         return x.view(B, N, -1)
 
+    def forward_rows_stacked(self, p1, p2, f1, f2, idx, nseg):
+        """`nseg` calls of this layer in one pass (calls stacked along the cloud axis, in call
+        order): p (nseg*B,N,3), f (nseg*B,N,C), idx (nseg*B,N,32) -> (nseg*B,N,mlp[-1])."""
+        C = f1.shape[-1]
+        NB, N, _ = p1.shape
+        with no_autocast(p1):
+            W = conv_weights_seg(self.mlp_convs[0], nseg).float()              # (nseg, C1, 3+2C)
+            U = rows_matmul_seg(torch.cat([p2.float(), f2.float()], dim=-1).view(NB * N, -1),
+                                W[:, :, :3 + C].contiguous()).view(NB, N, -1)
+            Q = (rows_matmul_seg(p1.float().reshape(NB * N, 3), W[:, :, :3].contiguous())
+                 - rows_matmul_seg(f1.float().reshape(NB * N, C), W[:, :, 3 + C:].contiguous())).view(NB, N, -1)
+        x = ops.row_combine(U, Q, idx, ops.ROW_SUB, out_dtype=amp_dtype(p1))     # (nseg*B,N,32,C1)
+        K = x.shape[2]
+        x = x.view(NB * N * K, -1)
+        nl = len(self.mlp_convs)
+        for l in range(nl):                                        # F.leaky_relu default slope 0.01
+            if l:
+                x = rows_matmul_seg(x, conv_weights_seg(self.mlp_convs[l], nseg))
+            x = bn_act_rows(self.mlp_bns[l], x, 0.01, K if l == nl - 1 else 0, nseg=nseg)
+        return x.view(NB, N, -1)
+
     def forward(self, pos1, pos2, feature1, feature2, radius):
         """Reference signature: pos (B,3,N), feature (B,C,N) -> pos1, (B,mlp[-1],N)."""
         out = self.forward_rows(pos1.transpose(1, 2).contiguous(), pos2.transpose(1, 2).contiguous(),
@@ -543,6 +593,31 @@ class FlowModule(nn.Module):
                      for l in range(len(feats) - 1)]
         assert len(feats) == 1
         return feats[0]
+
+    def depth_indices(self, pair_idx_per_pass, n_src):
+        """Neighbour lists of `forward_rows_passes`: for depth d the pairs 0..T-2-d of every pass,
+        stacked pass-major along the cloud axis (with their inverted index, ops.attach_inverse)."""
+        T1 = len(pair_idx_per_pass[0])
+        out = []
+        for d in range(self.depth):
+            idx = torch.cat([pairs[l] for pairs in pair_idx_per_pass for l in range(T1 - d)], 0).contiguous()
+            out.append(ops.attach_inverse(idx, n_src))
+        return out
+
+    def forward_rows_passes(self, feats, poss, depth_idx):
+        """NP passes x T frames at once: feats (NP,T,B,N,C), poss (NP,T,B,N,3) -> (NP*B,N,out).
+        Every depth runs its NP*(T-1-d) calls as segments of one pass (pass-major call order, the
+        order NP successive forward_rows calls would make them in)."""
+        NP, T = feats.shape[:2]
+        assert T == self.depth + 1
+        for d in range(self.depth):
+            n = T - 1 - d                                           # calls per pass at this depth
+            flat = lambda t: t.reshape(-1, *t.shape[3:])            # noqa: E731  (NP,n,B,..) -> (NP*n*B,..)
+            out = self.flow_emb_layers[d].forward_rows_stacked(
+                flat(poss[:, :n]), flat(poss[:, 1:n + 1]), flat(feats[:, :n]), flat(feats[:, 1:n + 1]),
+                depth_idx[d], NP * n)
+            feats = out.view(NP, n, out.shape[0] // (NP * n), *out.shape[1:])
+        return feats.reshape(-1, *feats.shape[3:])                  # n == 1 at the last depth
 
     def forward(self, feature_lst, pos_lst, cutoff):
         """Reference signature: lists of (B,C,N) / (B,3,N) -> (B,out,N)."""
@@ -631,16 +706,51 @@ class _TempoDis(nn.Module):
         poss2, feats2 = self.coarse_graining_module[1].forward_rows_frames(poss, feats, sa[1])
         return feats2, poss2
 
-    def _sn_calls(self, T):
-        """(module, calls in one forward over T frames) for every conv / linear."""
+    def _sn_calls(self, T, passes=1):
+        """(module, calls in `passes` forwards over T frames) for every conv / linear."""
         calls = []
         for sa in self.coarse_graining_module:
-            calls += [(m, T) for mlp in sa.mlps for m in mlp if isinstance(m, nn.Conv2d)]
+            calls += [(m, T * passes) for mlp in sa.mlps for m in mlp if isinstance(m, nn.Conv2d)]
         for d, layer in enumerate(self.flow_module.flow_emb_layers):
-            calls += [(m, T - 1 - d) for m in layer.mlp_convs]
-        calls += [(m, 1) for mlp in self.SA_pooling.mlps for m in mlp if isinstance(m, nn.Conv2d)]
-        calls += [(m, 1) for m in self.fc_layers.modules() if isinstance(m, nn.Linear)]
+            calls += [(m, (T - 1 - d) * passes) for m in layer.mlp_convs]
+        calls += [(m, passes) for mlp in self.SA_pooling.mlps for m in mlp if isinstance(m, nn.Conv2d)]
+        calls += [(m, passes) for m in self.fc_layers.modules() if isinstance(m, nn.Linear)]
         return calls
+
+    def merge_plans(self, plans):
+        """Index plans of successive forwards (same shapes) -> the plan of `forward_passes`."""
+        n0 = plans[0]["sa"][0][1]._tpg_inverse[0]
+        n1 = plans[0]["sa"][1][1]._tpg_inverse[0]
+        sa = []
+        for l, n_src in ((0, n0), (1, n1)):
+            c = torch.cat([p["sa"][l][0] for p in plans], 0)
+            i = ops.attach_inverse(torch.cat([p["sa"][l][1] for p in plans], 0).contiguous(), n_src)
+            sa.append((c, i))
+        n2 = plans[0]["flow"][0]._tpg_inverse[0]
+        return {"sa": sa, "flow_depth": self.flow_module.depth_indices([p["flow"] for p in plans], n2)}
+
+    def forward_passes(self, pos_lsts, cutoff, plan=None):
+        """[forward(pos_lst, cutoff) for pos_lst in pos_lsts] -- the same module calls in the same
+        order (so: the same spectral-norm iterations, BatchNorm statistics and running-statistic
+        updates) -- with the passes sharing their launches: every level, flow-embedding depth and
+        the pooling level run all passes (x frames) as segments of one batched pass.  Used for the
+        fake and the real batch of a discriminator update (train_step_final.py:171-204).
+        plan = merge_plans([index_plan(p, cutoff) for p in pos_lsts]) or None."""
+        NP, T, B = len(pos_lsts), len(pos_lsts[0]), pos_lsts[0][0].shape[0]
+        lvl0, lvl1 = self.coarse_graining_module
+        if not (rows_first() and lvl0.frames_stackable() and lvl1.frames_stackable() and pos_lsts[0][0].is_cuda):
+            assert plan is None
+            return [self.forward(p, cutoff) for p in pos_lsts]
+        with sn_prefetch(self._sn_calls(T, NP), self.training):
+            xyz = torch.cat([p.float() for pos_lst in pos_lsts for p in pos_lst], 0)        # (NP*T*B, N, 3)
+            if plan is None:
+                plan = self.merge_plans([self.index_plan(p, cutoff) for p in pos_lsts])
+            x1, f1 = lvl0.forward_rows_stacked(xyz, xyz, NP * T, plan["sa"][0])
+            x2, f2 = lvl1.forward_rows_stacked(x1, f1, NP * T, plan["sa"][1])
+            poss = x2.view(NP, T, B, *x2.shape[1:])
+            f = self.flow_module.forward_rows_passes(f2.view(NP, T, B, *f2.shape[1:]), poss, plan["flow_depth"])
+            pooled = self.SA_pooling.forward_rows_pool_stacked(poss[:, 0].reshape(NP * B, *x2.shape[1:]), f, NP)
+            return [_head_fp32(self.fc_layers, h) for h in pooled.view(NP, B, -1).unbind(0)]
 
     def _forward(self, pos_lst, cutoff, feat_lst, width, plan=None):
         if feat_lst is not None:
@@ -686,12 +796,38 @@ class FluidTempoDis(_TempoDis):
 
 
 class _SpatialDis(nn.Module):
-    def _sn_calls(self):
+    def _sn_calls(self, passes=1):
         calls = []
         for sa in list(self.coarse_graining_module) + [self.SA_pooling]:
-            calls += [(m, 1) for mlp in sa.mlps for m in mlp if isinstance(m, nn.Conv2d)]
-        calls += [(m, 1) for m in self.fc_layers.modules() if isinstance(m, nn.Linear)]
+            calls += [(m, passes) for mlp in sa.mlps for m in mlp if isinstance(m, nn.Conv2d)]
+        calls += [(m, passes) for m in self.fc_layers.modules() if isinstance(m, nn.Linear)]
         return calls
+
+    def merge_plans(self, plans):
+        """Index plans of successive forwards (same shapes) -> the plan of `forward_passes`."""
+        sa = []
+        for l in range(len(self.coarse_graining_module)):
+            n_src = plans[0]["sa"][l][1]._tpg_inverse[0]
+            c = torch.cat([p["sa"][l][0] for p in plans], 0)
+            sa.append((c, ops.attach_inverse(torch.cat([p["sa"][l][1] for p in plans], 0).contiguous(), n_src)))
+        return {"sa": sa}
+
+    def forward_passes(self, pos_list, plan=None):
+        """[forward(pos) for pos in pos_list] with the passes sharing their launches (see
+        _TempoDis.forward_passes)."""
+        NP, B = len(pos_list), pos_list[0].shape[0]
+        if not (rows_first() and pos_list[0].is_cuda and all(sa.frames_stackable() for sa in self.coarse_graining_module)):
+            assert plan is None
+            return [self.forward(p) for p in pos_list]
+        with sn_prefetch(self._sn_calls(NP), self.training):
+            pos = torch.cat([p.float() for p in pos_list], 0)
+            if plan is None:
+                plan = self.merge_plans([self.index_plan(p) for p in pos_list])
+            feature = None
+            for l, sa in enumerate(self.coarse_graining_module):
+                pos, feature = sa.forward_rows_stacked(pos, pos if feature is None else feature, NP, plan["sa"][l])
+            pooled = self.SA_pooling.forward_rows_pool_stacked(pos, feature, NP)
+            return [_head_fp32(self.fc_layers, h) for h in pooled.view(NP, B, -1).unbind(0)]
 
     def index_plan(self, pos):
         """FPS centres + ball-query lists of every level for the clouds `pos` (coordinates only)."""

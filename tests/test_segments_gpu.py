@@ -84,3 +84,70 @@ def test_segmented_tail_equals_per_frame_calls():
             continue
         ref = float(pb.grad.abs().max()) + 1e-12
         assert float((pa.grad - pb.grad).abs().max()) <= 2e-3 * ref, n
+
+
+def _no_dropout(m):
+    for sub in m.modules():
+        if isinstance(sub, torch.nn.Dropout):
+            sub.p = 0.0
+    return m
+
+
+def _compare_modules(ma, mb, outs_a, outs_b, rtol_out=2e-3):
+    for oa, ob in zip(outs_a, outs_b):
+        oa, ob = oa.detach().float(), ob.detach().float()
+        assert torch.allclose(oa, ob, rtol=rtol_out, atol=rtol_out * float(ob.abs().max() + 1e-6)), \
+            float((oa - ob).abs().max())
+    sd_a, sd_b = ma.state_dict(), mb.state_dict()
+    for k in sd_a:                          # running statistics, spectral-norm vectors, counters
+        assert torch.allclose(sd_a[k].float(), sd_b[k].float(), rtol=1e-4, atol=1e-5), k
+    ga = torch.cat([p.grad.reshape(-1) for (n, p), (_, q) in zip(ma.named_parameters(), mb.named_parameters())
+                    if p.grad is not None and q.grad is not None])
+    gb = torch.cat([q.grad.reshape(-1) for (n, p), (_, q) in zip(ma.named_parameters(), mb.named_parameters())
+                    if p.grad is not None and q.grad is not None])
+    assert float(gb.norm()) > 0
+    assert float((ga - gb).norm() / gb.norm()) <= 1e-2
+    for (n, p), (_, q) in zip(ma.named_parameters(), mb.named_parameters()):
+        if p.grad is None and q.grad is not None:      # conv bias ahead of a BatchNorm: folded, ~zero gradient
+            assert n.endswith("bias") and float(q.grad.abs().max()) <= 1e-3 * float(gb.abs().max()), n
+
+
+def test_tempo_discriminator_forward_passes_equals_two_forwards():
+    """fake + real batch as 2 x T segments of one pass == two successive forward calls (fp32)."""
+    from tpgan_amd.set_abstraction import FluidTempoDis
+    from tpgan_amd.synthetic import fluid_clip
+    torch.manual_seed(2)
+    dev = torch.device("cuda", 0)
+    Da = _no_dropout(FluidTempoDis(3)).to(dev).train()
+    Db = copy.deepcopy(Da)
+    _, hi1 = fluid_clip(4, 1024, 8, 3, seed=1, device=dev)
+    _, hi2 = fluid_clip(4, 1024, 8, 3, seed=2, device=dev)
+    fa = [h.clone().requires_grad_(True) for h in hi1]
+    fb = [h.clone().requires_grad_(True) for h in hi1]
+    outs_a = Da.forward_passes([fa, hi2], 0.1)
+    outs_b = [Db(fb, 0.1), Db(hi2, 0.1)]
+    la = ((outs_a[0] - 0.1) ** 2).mean() + ((outs_a[1] - 1.0) ** 2).mean()
+    lb = ((outs_b[0] - 0.1) ** 2).mean() + ((outs_b[1] - 1.0) ** 2).mean()
+    la.backward(); lb.backward()
+    _compare_modules(Da, Db, outs_a, outs_b)
+    for x, y in zip(fa, fb):    # gradient reaching the generator's points (L2: a max-pool arg-max
+        #                         flipping on a near-tie moves single entries by O(1))
+        assert float((x.grad - y.grad).norm() / (y.grad.norm() + 1e-12)) <= 3e-2
+
+
+def test_spatial_discriminator_forward_passes_equals_two_forwards():
+    from tpgan_amd.set_abstraction import FluidSpatialDis
+    from tpgan_amd.synthetic import fluid_clip
+    torch.manual_seed(3)
+    dev = torch.device("cuda", 0)
+    Da = _no_dropout(FluidSpatialDis()).to(dev).train()
+    Db = copy.deepcopy(Da)
+    _, hi1 = fluid_clip(4, 2048, 8, 3, seed=1, device=dev)
+    _, hi2 = fluid_clip(4, 2048, 8, 3, seed=2, device=dev)
+    a, b = hi1[1].clone().requires_grad_(True), hi1[1].clone().requires_grad_(True)
+    outs_a = Da.forward_passes([a, hi2[1]])
+    outs_b = [Db(b), Db(hi2[1])]
+    (((outs_a[0] - 0.1) ** 2).mean() + ((outs_a[1] - 1.0) ** 2).mean()).backward()
+    (((outs_b[0] - 0.1) ** 2).mean() + ((outs_b[1] - 1.0) ** 2).mean()).backward()
+    _compare_modules(Da, Db, outs_a, outs_b)
+    assert float((a.grad - b.grad).norm() / (b.grad.norm() + 1e-12)) <= 3e-2
