@@ -154,28 +154,33 @@ class GraphedFluidStep:
                 return trues, true_s, Dt.index_plan(trues, opt.R), Ds.index_plan(true_s)
             (k["trues"], k["true_s"], k["plan_true_t"], k["plan_true_s"]), k["join_real"] = \
                 run_index_plan(real_side, self.side)
+        # The generator has no cross-sample coupling (no BatchNorm): its T per-frame calls
+        # (train_step_final.py:116-150) are ONE call on the T*B stacked clouds, centre frame first.
+        order = [1] + others
         with _autocast(self.amp, self.dev):
-            edge, mask = G.body(low[1], low[1])
+            stacked = torch.cat([low[f] for f in order], 0)
+            edge_all, mask_all = G.body(stacked, stacked)
+        nT = len(order)                       # unbind: ONE stack in the backward instead of per-slice fills
+        edges = edge_all.reshape(nT, self.B, *edge_all.shape[1:]).unbind(0)
+        masks = mask_all.reshape(nT, self.B, *mask_all.shape[1:]).unbind(0)
+        edge, mask = edges[0], masks[0]
         pred_c, padded_c, keep_c = G.expand_pos_static(low[1], edge, mask)
         fake_s_in = padded_c.index_select(1, self.perm_c).float()
-        plan_fs, join_fs = self._plan(lambda: Ds.index_plan(fake_s_in))     # overlaps the other frames
+        plan_fs, join_fs = self._plan(lambda: Ds.index_plan(fake_s_in))
         position_loss, cd, ml = tpugan_sr_loss(100., high[1], pred_c.float(), low[1], mask.float(),
                                                opt.cutoff / self.fd, 11)
         viol = ~(ml.reshape(()) < 0.1) | ~keep_c                   # NaN counts as a violation
         with _frozen(Ds, Dt), _autocast(self.amp, self.dev):
-            edge_o, mask_o = G.body(torch.cat([low[f] for f in others], 0), torch.cat([low[f] for f in others], 0))
             pred_lst = [None] * self.T
             pred_lst[1] = padded_c
-            n_o = len(others)               # unbind: ONE stack in the backward instead of per-slice fills
-            edges = edge_o.reshape(n_o, self.B, *edge_o.shape[1:]).unbind(0)
-            masks = mask_o.reshape(n_o, self.B, *mask_o.shape[1:]).unbind(0)
             for i, f in enumerate(others):
-                _, padded, keep = G.expand_pos_static(low[f], edges[i], masks[i])
+                _, padded, keep = G.expand_pos_static(low[f], edges[i + 1], masks[i + 1])
                 viol = viol | ~keep
                 pred_lst[f] = padded.index_select(1, self.perm_f[i])
                 last_padded = padded
             fake_t_in = [p.float() for p in pred_lst]
-            plan_ft, join_ft = self._plan(lambda: Dt.index_plan(fake_t_in, opt.R))   # overlaps D_spatial
+            # (merged plan of ONE pass: the frames and frame pairs still run as segments)
+            plan_ft, join_ft = self._plan(lambda: Dt.merge_plans([Dt.index_plan(fake_t_in, opt.R)]))   # overlaps D_spatial
             if update_D:
                 def fake_side():
                     fakes = [torch.matmul(p.detach(), self.rot_fake_t[f]) for f, p in enumerate(fake_t_in)]
@@ -191,7 +196,7 @@ class GraphedFluidStep:
             fake = Ds(fake_s_in, plan=plan_fs)
             spatial_loss = (0.5 * (fake.float() - lab[2]) ** 2).mean()
             join_ft()
-            fake = Dt(fake_t_in, opt.R, plan=plan_ft)
+            fake = Dt.forward_passes([fake_t_in], opt.R, plan=plan_ft)[0]
             tempo_loss = (0.5 * (fake.float() - lab[3]) ** 2).mean()
         sr_loss = tempo_loss + spatial_loss + opt.w * position_loss
         self.og.zero_grad(set_to_none=True)
