@@ -69,6 +69,7 @@ def build(device, seed=1, capturable=False):
 
 
 GRAPHED = None   # GraphedFluidStep when the hipGraph path is active
+EAGER_BODY = False   # --eager-body: run the captured step body launch by launch (for PMC passes)
 TRACE = bool(os.environ.get("TPGAN_BENCH_TRACE"))
 
 
@@ -77,7 +78,9 @@ def run_steps(models, clips, n, sync, amp_dtype, start=0):
     out = None
     for i in range(n):
         low, high = clips[(start + i) % len(clips)]
-        if GRAPHED is not None and low[0].is_cuda:
+        if GRAPHED is not None and low[0].is_cuda and EAGER_BODY:
+            out = GRAPHED.run_body_eagerly(low, high)
+        elif GRAPHED is not None and low[0].is_cuda:
             out = GRAPHED(low, high, 12)
         else:
             out = tempo_gan_step(G, Ds, Dt, low, None, high, None, 1.0, OPT, 12, og, ot, os_,
@@ -121,7 +124,11 @@ def roofline_leg(models, clips, steps, sync, amp_dtype):
     ops.set_timer(timer)
     saved, GRAPHED = GRAPHED, None
     try:
-        run_steps(models, clips, steps, sync, amp_dtype)
+        if saved is not None:            # the body the graphs replay, kernel by kernel
+            for i in range(steps):
+                saved.run_body_eagerly(*clips[i % len(clips)])
+        else:
+            run_steps(models, clips, steps, sync, amp_dtype)
         torch.cuda.synchronize()
     finally:
         ops.set_timer(None)
@@ -138,7 +145,7 @@ def roofline_leg(models, clips, steps, sync, amp_dtype):
             "avg_launch_us": round(dom["avg_us"], 2), "launches_per_step": dom["launches"] / steps,
             "algorithmic_bytes_per_launch": int(dom["bytes_per_launch"]),
             "selection": "largest total time among the HBM-streaming kernels; timed per launch with HIP "
-                         "events in an eager (non-graph) pass over the same steps"}
+                         "events while the captured step body runs eagerly (launch by launch)"}
     table = {k: {"launches_per_step": v["launches"] / steps, "ms_per_step": round(v["total_ms"] / steps, 4),
                  "avg_us": round(v["avg_us"], 2), "GBps": round(v["gbps"], 1)} for k, v in summ.items()}
     if "fps" in summ:
@@ -170,6 +177,9 @@ def main():
     ap.add_argument("--cpu-sample-batch", type=int, default=4)
     ap.add_argument("--no-graph", action="store_true",
                     help="run the step eagerly instead of replaying it from captured hipGraphs")
+    ap.add_argument("--eager-body", action="store_true",
+                    help="build the graphed step but run its body launch by launch (for rocprofv3 PMC "
+                         "passes: per-kernel counters of the exact launches the graphs replay)")
     ap.add_argument("--miopen", action="store_true",
                     help="let PyTorch use MIOpen for conv/BN (first use JIT-compiles per shape: minutes)")
     args = ap.parse_args()
@@ -192,7 +202,8 @@ def main():
     sync.broadcast_state(*models[:3])
     clips = [fluid_clip(args.batch, args.points, 8, 3, seed=1234 + rank * 1000 + s, device=device)
              for s in range(4)]
-    global GRAPHED
+    global GRAPHED, EAGER_BODY
+    EAGER_BODY = bool(args.eager_body)
     mode = "eager"
     if not args.no_graph:
         try:
@@ -203,6 +214,8 @@ def main():
         except Exception as e:   # noqa: BLE001 -- never lose the measurement to a capture problem
             GRAPHED = None
             log(f"hipGraph capture failed ({type(e).__name__}: {e}); running eagerly")
+    if EAGER_BODY and GRAPHED is not None:
+        mode = "captured step body, launched eagerly"
     log(f"rank {rank}: step mode = {mode}")
 
     log(f"rank {rank}: models and clips resident, warming up")

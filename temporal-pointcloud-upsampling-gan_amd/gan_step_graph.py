@@ -370,6 +370,16 @@ class GraphedFluidStep:
                 "spatial_D_loss"]
         return dict(zip(keys, out[:6]))
 
+    def run_body_eagerly(self, lowres_pos_lst, highres_pos_lst, update_D=True):
+        """One step through the SAME body the graphs were captured from, launched kernel by kernel
+        (bench.py's per-kernel timing leg; host draws stay at their last values)."""
+        self._load(lowres_pos_lst, highres_pos_lst)
+        self._run_eager(update_D)
+        torch.cuda.synchronize(self.dev)
+        keys = ["tempo_G_loss", "tempo_D_loss", "Chamfer_distance_no_norm", "masking_loss", "spatial_G_loss",
+                "spatial_D_loss"]
+        return dict(zip(keys, self.report.cpu().tolist()))
+
     def _eager(self, low, high, n_iter, freeze_D):
         return tempo_gan_step(self.G, self.Ds, self.Dt, low, None, high, None, self.fd, self.opt, n_iter, self.og,
                               self.ot, self.os, freeze_D, sync=self.sync, amp_dtype=self.amp)

@@ -1,8 +1,8 @@
 """Turns two rocprofv3 PMC passes (FETCH_SIZE and WRITE_SIZE, collected separately as the
 MI355X guide prescribes) into HBM bytes per launch for the kernels of interest.
 
-    rocprofv3 --kernel-trace --pmc FETCH_SIZE --output-format csv -d gpurun_out/pmc_fetch -- python3 bench.py ... --no-graph
-    rocprofv3 --kernel-trace --pmc WRITE_SIZE --output-format csv -d gpurun_out/pmc_write -- python3 bench.py ... --no-graph
+    rocprofv3 --kernel-trace --pmc FETCH_SIZE --output-format csv -d gpurun_out/pmc_fetch -- python3 bench.py ... --eager-body
+    rocprofv3 --kernel-trace --pmc WRITE_SIZE --output-format csv -d gpurun_out/pmc_write -- python3 bench.py ... --eager-body
     python tools/pmc_traffic.py gpurun_out/pmc_fetch gpurun_out/pmc_write > profiles/r01_pmc_traffic.json
 
 FETCH_SIZE / WRITE_SIZE are in KiB.  gfx950 correction (MI355X_MICROARCH.md, HBM section): FETCH_SIZE
@@ -15,7 +15,7 @@ import json
 import sys
 
 KERNELS = {  # bench op name -> substring of the kernel symbol
-    "rowbn_bwd_apply": "rowbn_bwd_apply_kernel",
+    "rowbn_bwd_apply": "rowbn_bwd_apply",        # plain and max variant
     "rowbn_bwd_reduce": "rowbn_bwd_reduce",
     "rowbn_fwd_stats": "rowbn_stats_kernel",
     "rowbn_fwd_apply": "rowbn_apply_kernel",
