@@ -203,6 +203,21 @@ int tpg_spectral_norm_multi_fwd(const void *desc, int M, int max_rc, float *out,
 int tpg_spectral_norm_multi_bwd(const void *desc, int M, const float *g, const float *out, float *dw,
                                 void *stream);
 
+/* ---- fused radius search + bicubic weighted average (the `--use_vel` advection features) ----
+ * gcn_lib/interpolation.py:107-123 `cubic_interpolation(query_pos, field, pos, cutoff)` over
+ * get_local_neighbor_graph (:16-75; FRNN K=32, unique, FRNN, kNN-4 padding, DGL scatter-sums),
+ * called per frame and per sample by train_step_final.py:51-66.  query (B,Nq,3), pos (B,Np,3),
+ * field (B,Np,F).  Per query: the <= 32 nearest field points with d^2 < cutoff^2 (ascending
+ * (d^2, idx)), w = bicubic(d / cutoff) * 8 / (pi cutoff^3);
+ *   out_plain = sum w f / (sum w + 1e-6)
+ *   out_pad   = the same with the 4 nearest hits counted twice (the reference's padding edges)
+ *   hits      = number of in-range neighbours found (<= 32)
+ * The caller picks out_pad for the queries with hits < 32 of every cloud in which SOME query has
+ * hits == 0 (that is when the reference adds its padding edges), out_plain otherwise. */
+int tpg_cubic_interp_f32(const float *query, const float *pos, const float *field, int B, int Nq, int Np,
+                         int F, float cutoff, float *out_plain, float *out_pad, int32_t *hits,
+                         void *stream);
+
 #ifdef __cplusplus
 }
 #endif

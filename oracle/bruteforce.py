@@ -117,3 +117,58 @@ def chamfer(src, tgt):
 def three_nn(unknown, known):
     d, i = knn(unknown, known, 3)
     return d, i.astype(np.int32)
+
+
+# ---- cubic interpolation: the reference's algorithm step by step ---------------------------
+def _frnn_lists(query, cand, r, K=32):
+    """Per query: indices of the <=K nearest candidates with d^2 < fp32(r)^2, ascending (d^2, idx)."""
+    r2 = np.float32(np.float32(r) * np.float32(r))
+    out = []
+    for q in query.astype(np.float32):
+        d = ((q[None, :] - cand.astype(np.float32)) ** 2)
+        d2 = (d[:, 0] + d[:, 1]) + d[:, 2]                     # fp32, d order
+        order = np.lexsort((np.arange(len(cand)), d2))
+        out.append([int(j) for j in order if d2[j] < r2][:K])
+    return out
+
+
+def _bicubic(r, cutoff):
+    coeff = 8. / (np.pi * cutoff ** 3)
+    q = (r / np.float32(cutoff)).astype(np.float32)
+    ker = np.zeros_like(q)
+    m1 = (q >= 0) & (q <= 0.5)
+    m2 = (q > 0.5) & (q <= 1)
+    ker[m1] = (6. * (q ** 3 - q ** 2) + 1.)[m1]
+    ker[m2] = (2. * (1. - q) ** 3)[m2]
+    return (ker * np.float32(coeff)).astype(np.float32)
+
+
+def cubic_interpolation(query, field, pos, cutoff):
+    """gcn_lib/interpolation.py:107-123 + :16-75 for ONE sample, as a literal edge list (a multigraph:
+    the kNN-4 padding adds edges without removing duplicates).  query (Nq,3), field (Np,F), pos (Np,3)."""
+    query, field, pos = (np.asarray(a, np.float32) for a in (query, field, pos))
+    first = _frnn_lists(query, pos, cutoff)
+    in_range = np.unique(np.array([j for l in first for j in l], dtype=np.int64))   # filter_out_of_range
+    cand, fld = pos[in_range], field[in_range]
+    lists = _frnn_lists(query, cand, cutoff)
+    src = [j for l in lists for j in l]
+    dst = [q for q, l in enumerate(lists) for _ in l]
+    if any(len(l) == 0 for l in lists):                                                 # knn_padding
+        for q, l in enumerate(lists):
+            if len(l) < 32:
+                d = ((query[q][None, :] - cand) ** 2)
+                d2 = (d[:, 0] + d[:, 1]) + d[:, 2]
+                near = np.lexsort((np.arange(len(cand)), d2))[:4]
+                src += [int(j) for j in near]
+                dst += [q] * len(near)
+    out = np.zeros((len(query), field.shape[1]), np.float64)
+    k = np.zeros(len(query), np.float64)
+    if src:
+        src, dst = np.array(src), np.array(dst)
+        a, b = cand[src], query[dst]
+        dist = (a ** 2 + b ** 2 - 2 * b * a).sum(1)                                   # l2dist :11-14
+        dist[dist < 1e-8] = 0.
+        w = _bicubic(np.sqrt(dist.astype(np.float32)), cutoff).astype(np.float64)
+        np.add.at(out, dst, w[:, None] * fld[src].astype(np.float64))
+        np.add.at(k, dst, w)
+    return (out / (k[:, None] + 1e-6)).astype(np.float32)

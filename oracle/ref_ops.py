@@ -63,6 +63,18 @@ def knn(p1, p2, K, lengths1=None, lengths2=None, r=None):
     return dist, idx
 
 
+def cubic_interp(query, pos, field, cutoff):
+    """-> (out_plain (B,Nq,F), out_pad (B,Nq,F), hits (B,Nq) i32); include/tpgan_ops.h."""
+    query, pos, field = _c(query, np.float32), _c(pos, np.float32), _c(field, np.float32)
+    B, Nq, _ = query.shape
+    Np, F = pos.shape[1], field.shape[2]
+    plain, pad = np.empty((B, Nq, F), np.float32), np.empty((B, Nq, F), np.float32)
+    hits = np.empty((B, Nq), np.int32)
+    _chk(lib().tpgref_cubic_interp_f32(_f(query), _f(pos), _f(field), B, Nq, Np, F, C.c_float(cutoff),
+                                       _f(plain), _f(pad), _i32(hits)), "cubic_interp")
+    return plain, pad, hits
+
+
 def chamfer_fwd(src, tgt):
     src, tgt = _c(src, np.float32), _c(tgt, np.float32)
     B, N, _ = src.shape

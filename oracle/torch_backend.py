@@ -84,6 +84,10 @@ class OracleBackend:
         return _t(gU).to(in_dtype), (None if gQE is None else _t(gQE).to(in_dtype))
 
 
+    def cubic_interp(self, query, pos, field, cutoff):
+        plain, pad, hits = R.cubic_interp(_np(query), _np(pos), _np(field), cutoff)
+        return _t(plain), _t(pad), _t(hits)
+
     # ---- fused BatchNorm + act (+max) on rows ---------------------------------------------
     def rowbn_fwd(self, x, K, eps, momentum, training, running_mean, running_var, gamma, beta, slope, mean,
                   rstd, out_dtype, num_batches_tracked=None, nseg=1, mean_shift=None):

@@ -396,3 +396,67 @@ int tpgref_rowcombine_bwd_f32(const float *gout, const int32_t *idx, const float
             }
     return TPG_OK;
 }
+
+/* ------------------------------------------------------------------------ */
+/* Bicubic radius interpolation: gcn_lib/interpolation.py:107-123            */
+/* (cubic_interpolation) over get_local_neighbor_graph :16-75, as called by  */
+/* train_step_final.py:51-66.  See include/tpgan_ops.h for the reduction of  */
+/* the DGL graph to per-query sums; sums here run sequentially over the      */
+/* neighbours in ascending (d^2, idx) order.                                 */
+/* ------------------------------------------------------------------------ */
+static float bicubic_w(float r, float cutoff, float coeff) {
+    const float q = r / cutoff;
+    float ker = 0.0f;
+    if (q >= 0.0f && q <= 0.5f) ker = 6.0f * (q * q * q - q * q) + 1.0f;
+    else if (q > 0.5f && q <= 1.0f) { const float t = 1.0f - q; ker = 2.0f * (t * t * t); }
+    return ker * coeff;
+}
+
+int tpgref_cubic_interp_f32(const float *query, const float *pos, const float *field, int B, int Nq,
+                            int Np, int F, float cutoff, float *out_plain, float *out_pad,
+                            int32_t *hits) {
+    if (B < 0 || Nq < 0 || Np < 0 || F <= 0 || !(cutoff > 0.0f)) return TPG_ERR_ARG;
+    enum { K = 32 };
+    const float r2 = cutoff * cutoff;
+    const float coeff = (float)(8.0 / (3.14159265358979323846 * (double)cutoff * (double)cutoff * (double)cutoff));
+    const size_t nq = (size_t)B * Nq;
+    float *dist = (float *)malloc(sizeof(float) * (nq * K + 1));
+    int64_t *idx = (int64_t *)malloc(sizeof(int64_t) * (nq * K + 1));
+    if (!dist || !idx) { free(dist); free(idx); return TPG_ERR_ARG; }
+    int rc = tpgref_knn_f32(query, pos, NULL, NULL, B, Nq, Np, 3, K, r2, dist, idx);
+    if (rc == TPG_OK) {
+#pragma omp parallel for schedule(static)
+        for (long long t = 0; t < (long long)nq; ++t) {
+            const int b = (int)(t / Nq);
+            const float *fb = field + (size_t)b * Np * F;
+            int nh = 0;
+            double den = 0.0, denp = 0.0;
+            for (int f = 0; f < F; ++f) { out_plain[t * F + f] = 0.0f; out_pad[t * F + f] = 0.0f; }
+            /* two passes keep the sums in double: the kernel's tree order differs anyway */
+            double num[16], nump[16];
+            const int FF = F < 16 ? F : 16;
+            for (int f = 0; f < FF; ++f) { num[f] = 0.0; nump[f] = 0.0; }
+            for (int k = 0; k < K; ++k) {
+                const int64_t j = idx[t * K + k];
+                if (j < 0) break;
+                float d2 = dist[t * K + k];
+                if (d2 < 1e-8f) d2 = 0.0f;
+                const float w = bicubic_w(sqrtf(d2), cutoff, coeff);
+                const float wp = k < 4 ? 2.0f * w : w;
+                den += w; denp += wp;
+                for (int f = 0; f < FF; ++f) {
+                    num[f] += (double)(w * fb[(size_t)j * F + f]);
+                    nump[f] += (double)(wp * fb[(size_t)j * F + f]);
+                }
+                ++nh;
+            }
+            for (int f = 0; f < FF; ++f) {
+                out_plain[t * F + f] = (float)(num[f] / (den + 1e-6));
+                out_pad[t * F + f] = (float)(nump[f] / (denp + 1e-6));
+            }
+            hits[t] = nh;
+        }
+    }
+    free(dist); free(idx);
+    return rc;
+}

@@ -13,13 +13,15 @@ run can be compared draw for draw with the reference.  What is organised differe
   * the gate `ml < 0.1` (:117,:166) and the gradients are reduced over the ranks by
     `sync` (see ddp.py), so every rank takes the same branch and the same optimizer step;
   * the six `.item()` host syncs at the end (:222-229) collapse into one transfer;
-  * `--use_vel` (cubic_interpolation, gcn_lib/interpolation.py) is a "next" row and raises.
+  * `--use_vel`: the advection features come from ONE fused search-and-sum launch for all frames
+    and samples (interpolation.interpolate_vel_lst) instead of a DGL graph per frame and sample.
 """
 import contextlib
 
 import numpy as np
 import torch
 
+from .interpolation import interpolate_vel_lst
 from .losses import tpugan_sr_loss
 
 DT = 0.025
@@ -37,13 +39,16 @@ def get_rotation_matrix(device=None):
     return torch.matmul(Rz, torch.matmul(Ry, Rx)).to(device)
 
 
-def rotate_lst(pos_lst):
-    """One fresh random rotation per frame, shared by the batch (train_step_final.py:38-48)."""
-    out = []
-    for pos in pos_lst:
+def rotate_lst(pos_lst, vel_lst=None):
+    """One fresh random rotation per frame, shared by the batch and -- with `vel_lst` -- by the
+    frame's velocity-like features (train_step_final.py:38-48)."""
+    out, vout = [], []
+    for i, pos in enumerate(pos_lst):
         r0 = get_rotation_matrix(pos.device).unsqueeze(0)
         out.append(torch.bmm(pos, r0.expand(pos.shape[0], -1, -1)))
-    return out
+        if vel_lst is not None:
+            vout.append(torch.bmm(vel_lst[i], r0.expand(pos.shape[0], -1, -1)))
+    return out if vel_lst is None else (out, vout)
 
 
 def _per_sample_rotation(pos):
@@ -100,11 +105,16 @@ def tempo_gan_step(sr_net, spatial_dis, tempo_dis, lowres_pos_lst, lowres_vel_ls
 
     force_gate: treat the gate `ml < 0.1` as open regardless of `ml` (benchmark regime,
     SURVEY.md section 8d); everything else is unchanged."""
-    if getattr(opt, "use_vel", False):
-        raise NotImplementedError("--use_vel needs cubic_interpolation (SURVEY.md section 8f row 1)")
+    use_vel = bool(getattr(opt, "use_vel", False))
     sync = sync or _NoSync()
     dev = lowres_pos_lst[1].device
     T = len(highres_pos_lst)
+
+    def g_input(f):
+        """Generator features of frame f (train_step_final.py:96-104,130-137)."""
+        if use_vel and getattr(opt, "in_node_feats", 3) == 6:
+            return torch.cat([lowres_pos_lst[f], lowres_vel_lst[f] * DT], dim=2)
+        return lowres_pos_lst[f]
 
     valid = np.random.uniform(0.8, 1.2)
     invalid = np.random.uniform(0.0, 0.2)
@@ -113,7 +123,7 @@ def tempo_gan_step(sr_net, spatial_dis, tempo_dis, lowres_pos_lst, lowres_vel_ls
 
     low_c = lowres_pos_lst[1]
     with _autocast(amp_dtype, dev):
-        pred_c, mask_c, padded_c = sr_net(low_c, low_c, hard_masking=True)
+        pred_c, mask_c, padded_c = sr_net(g_input(1), low_c, hard_masking=True)
     high_c = highres_pos_lst[1]
     position_loss, cd, ml = tpugan_sr_loss(100., high_c, pred_c.float(), low_c, mask_c.float(),
                                            opt.cutoff / furthest_distance, n_iter)
@@ -128,7 +138,7 @@ def tempo_gan_step(sr_net, spatial_dis, tempo_dis, lowres_pos_lst, lowres_vel_ls
             fake = spatial_dis(padded_c[:, torch.randperm(padded_c.shape[1])].float())
             spatial_loss = (0.5 * (fake.float() - np.random.uniform(0.8, 1.2)) ** 2).mean()
             others = [0] + list(range(2, T))
-            outs = sr_net.forward_frames([lowres_pos_lst[f] for f in others],
+            outs = sr_net.forward_frames([g_input(f) for f in others],
                                          [lowres_pos_lst[f] for f in others], hard_masking=True)
             pred_pos_lst = [None] * T
             pred_pos_lst[1] = padded_c
@@ -138,7 +148,12 @@ def tempo_gan_step(sr_net, spatial_dis, tempo_dis, lowres_pos_lst, lowres_vel_ls
             last_may_pad = bool(sr_net.last_pad_flags[-1])
             any_pad = may_pad or any(sr_net.last_pad_flags)
             _set_dummy_check(tempo_dis, any_pad)
-            fake = tempo_dis([p.float() for p in pred_pos_lst], opt.R)
+            if use_vel:      # advection features: real ones and their interpolation at the predictions
+                gt_adv_lst, pred_adv_lst = interpolate_vel_lst(pred_pos_lst, highres_pos_lst, highres_vel_lst,
+                                                               opt, furthest_distance)
+                fake = tempo_dis([p.float() for p in pred_pos_lst], opt.R, feat_lst=pred_adv_lst)
+            else:
+                fake = tempo_dis([p.float() for p in pred_pos_lst], opt.R)
             tempo_loss = (0.5 * (fake.float() - np.random.uniform(0.8, 1.2)) ** 2).mean()
     else:
         spatial_loss, tempo_loss = zero, zero
@@ -152,14 +167,23 @@ def tempo_gan_step(sr_net, spatial_dis, tempo_dis, lowres_pos_lst, lowres_vel_ls
     if n_iter % 2 == 0 and not freeze_D and gate:
         fakes = [p.detach().float() for p in pred_pos_lst]
         trues = list(highres_pos_lst)
+        fake_kw, true_kw = {}, {}
+        if use_vel:
+            fake_adv, true_adv = pred_adv_lst, gt_adv_lst
         if np.random.uniform() > 0.7:
-            fakes = rotate_lst(fakes)
-            trues = rotate_lst(trues)
+            if use_vel:                 # positions and advection features of a frame turn together
+                fakes, fake_adv = rotate_lst(fakes, fake_adv)
+                trues, true_adv = rotate_lst(trues, true_adv)
+            else:
+                fakes = rotate_lst(fakes)
+                trues = rotate_lst(trues)
+        if use_vel:
+            fake_kw, true_kw = {"feat_lst": fake_adv}, {"feat_lst": true_adv}
         _set_dummy_check(tempo_dis, any_pad)
         with _autocast(amp_dtype, dev):
-            fake = tempo_dis(fakes, opt.R)
+            fake = tempo_dis(fakes, opt.R, **fake_kw)
             _set_dummy_check(tempo_dis, False)                       # real clouds never hold dummies
-            true = tempo_dis(trues, opt.R)
+            true = tempo_dis(trues, opt.R, **true_kw)
         tempo_dis_loss = (0.5 * ((true.float() - valid) ** 2 + (fake.float() - invalid) ** 2)).mean()
         tempo_dis_optim.zero_grad()
         tempo_dis_loss.backward()

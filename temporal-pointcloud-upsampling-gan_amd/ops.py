@@ -136,6 +136,17 @@ class HipBackend:
                    -1.0 if r2 is None else r2, _ptr(dist), _ptr(idx))
         return dist, idx
 
+    def cubic_interp(self, query, pos, field, cutoff):
+        B, Nq, _ = query.shape
+        Np, F_ = pos.shape[1], field.shape[2]
+        plain = torch.empty((B, Nq, F_), dtype=torch.float32, device=query.device)
+        pad = torch.empty_like(plain)
+        hits = torch.empty((B, Nq), dtype=torch.int32, device=query.device)
+        self._call("tpg_cubic_interp_f32", "cubic_interp", 12 * B * (Nq + Np) + 4 * B * Np * F_ + 8 * B * Nq * F_,
+                   query, _ptr(query), _ptr(pos), _ptr(field), B, Nq, Np, F_, float(cutoff), _ptr(plain),
+                   _ptr(pad), _ptr(hits))
+        return plain, pad, hits
+
     def chamfer_fwd(self, src, tgt):
         B, N, _ = src.shape
         M = tgt.shape[1]
@@ -545,6 +556,32 @@ def neighbour_search(p1, p2, K, lengths1=None, lengths2=None, r=None):
     l2 = _lengths(lengths2, B, b.shape[1], a.device)
     r2 = None if r is None else radius_sq(r)
     return backend_for(a).knn(a, b, l1, l2, int(K), r2)
+
+
+def cubic_interpolation(query_pos, field, pos, cutoff):
+    """Bicubic-kernel interpolation of `field` (given at `pos`) at `query_pos` within `cutoff`:
+    gcn_lib/interpolation.py:107-123 for a whole batch in one launch (the reference loops over
+    frames and samples in Python, train_step_final.py:51-66, building a DGL graph per call).
+
+    query_pos (B,Nq,3), field (B,Np,F), pos (B,Np,3) -> (B,Nq,F); unbatched 2-D inputs are
+    accepted like the reference's and return (Nq,F).  No gradient (the reference calls it under
+    no_grad).  Includes the reference's kNN-padding rule: in a cloud where some query has no
+    field point within the cutoff, every query with fewer than 32 hits counts its 4 nearest hits
+    twice (include/tpgan_ops.h)."""
+    squeeze = query_pos.dim() == 2
+    if squeeze:
+        query_pos, field, pos = query_pos.unsqueeze(0), field.unsqueeze(0), pos.unsqueeze(0)
+    _need(query_pos.dim() == 3 and pos.dim() == 3 and field.dim() == 3, "query (B,Nq,3), field (B,Np,F), pos (B,Np,3)")
+    _need(query_pos.shape[2] == 3 and pos.shape[2] == 3 and field.shape[:2] == pos.shape[:2]
+          and query_pos.shape[0] == pos.shape[0], "shape mismatch")
+    _same_device(query_pos, pos)
+    q = query_pos.detach().float().contiguous()
+    p = pos.detach().float().contiguous()
+    f = field.detach().float().contiguous()
+    plain, pad, hits = backend_for(q).cubic_interp(q, p, f, float(cutoff))
+    padded_cloud = (hits == 0).any(dim=1, keepdim=True)                  # some query without any hit
+    out = torch.where((padded_cloud & (hits < 32)).unsqueeze(-1), pad, plain)
+    return out[0] if squeeze else out
 
 
 class _KnnDists(torch.autograd.Function):

@@ -19,8 +19,10 @@ def fluid_ball_radius(n_hi):
     return (3.0 * n_hi * SPACING ** 3 / (4.0 * math.pi)) ** (1.0 / 3.0)
 
 
-def fluid_clip(batch, n_hi=4096, ratio=8, frames=3, seed=1234, device="cpu"):
-    """-> (lowres_pos_lst, highres_pos_lst): lists of `frames` tensors (B,N_lo,3) / (B,N_hi,3)."""
+def fluid_clip(batch, n_hi=4096, ratio=8, frames=3, seed=1234, device="cpu", with_vel=False):
+    """-> (lowres_pos_lst, highres_pos_lst): lists of `frames` tensors (B,N_lo,3) / (B,N_hi,3);
+    with_vel: -> (low_pos, high_pos, low_vel, high_vel), the particle velocities per frame (the
+    `--use_vel` inputs of tempo_gan_step)."""
     g = torch.Generator(device="cpu").manual_seed(int(seed))
     R = fluid_ball_radius(n_hi)
     # uniform in a ball: direction ~ normal, radius ~ R * u^(1/3)
@@ -35,6 +37,10 @@ def fluid_clip(batch, n_hi=4096, ratio=8, frames=3, seed=1234, device="cpu"):
         high.append(p.to(device).contiguous())
         lo = p[:, ::ratio] + 0.003 * torch.randn(batch, n_hi // ratio, 3, generator=g)
         low.append(lo.to(device).contiguous())
+    if with_vel:
+        v = vel.expand(batch, n_hi, 3).contiguous()
+        return (low, high, [v[:, ::ratio].contiguous().to(device) for _ in range(frames)],
+                [v.to(device) for _ in range(frames)])
     return low, high
 
 

@@ -359,3 +359,59 @@ def test_both_orders_give_the_same_gradients(oracle_cpu):
 @pytest.mark.parametrize("kind", ["fluid_keep", "fluid_init", "action"])
 def test_train_step_gpu(kind):
     run_step(kind, "cuda", 2e-4)
+
+
+def test_use_vel_step_runs_on_the_oracle_backend(oracle_cpu):
+    """`--use_vel` (train_step_final.py:96-104,147-150,171-181): advection features through the fused
+    interpolation, generator input [pos | vel*DT] with in_node_feats = 6.  No golden exists (the
+    reference needs DGL for this path: PARITY UNPINNED); the interpolation itself is checked against
+    the reference's algorithm in tests/test_oracle_cpu.py."""
+    import numpy as np
+    import torch
+    from argparse import Namespace
+    from tpgan_amd.gan_step import tempo_gan_step
+    from tpgan_amd.set_abstraction import FluidSpatialDis, FluidTempoDis
+    from tpgan_amd.srnet import SRNet
+    from tpgan_amd.synthetic import fluid_clip, force_all_keep
+    torch.manual_seed(0); np.random.seed(0)
+    G = force_all_keep(SRNet(6, 128))
+    Ds, Dt = FluidSpatialDis(), FluidTempoDis(3)
+    opts = [torch.optim.Adam(m.parameters(), lr=1e-4) for m in (G, Dt, Ds)]
+    low, high, lvel, hvel = fluid_clip(2, 1024, 8, 3, seed=3, with_vel=True)
+    opt = Namespace(use_vel=True, in_node_feats=6, cutoff=0.025, R=0.10, w=0.5)
+    before = [p.detach().clone() for p in Dt.parameters()]
+    out = tempo_gan_step(G, Ds, Dt, low, lvel, high, hvel, 1.0, opt, 12, opts[0], opts[1], opts[2], force_gate=True)
+    assert all(np.isfinite(v) for v in out.values()) and out["tempo_D_loss"] > 0
+    assert any(not torch.equal(a, b) for a, b in zip(before, Dt.parameters()))
+    # the discriminator really saw the advection features: same seeds without them -> another loss
+    torch.manual_seed(0); np.random.seed(0)
+    G2 = force_all_keep(SRNet(6, 128))
+    Ds2, Dt2 = FluidSpatialDis(), FluidTempoDis(3)
+    opts2 = [torch.optim.Adam(m.parameters(), lr=1e-4) for m in (G2, Dt2, Ds2)]
+    hvel0 = [torch.zeros_like(v) for v in hvel]
+    out0 = tempo_gan_step(G2, Ds2, Dt2, low, lvel, high, hvel0, 1.0, opt, 12, opts2[0], opts2[1], opts2[2],
+                          force_gate=True)
+    assert abs(out0["tempo_G_loss"] - out["tempo_G_loss"]) > 1e-6
+
+
+@pytest.mark.gpu
+def test_use_vel_step_runs_on_the_gpu():
+    import numpy as np
+    import torch
+    from argparse import Namespace
+    from tpgan_amd.gan_step import tempo_gan_step
+    from tpgan_amd.set_abstraction import FluidSpatialDis, FluidTempoDis
+    from tpgan_amd.srnet import SRNet
+    from tpgan_amd.synthetic import fluid_clip, force_all_keep
+    dev = torch.device("cuda", 0)
+    torch.manual_seed(0); np.random.seed(0)
+    G = force_all_keep(SRNet(6, 128)).to(dev)
+    Ds, Dt = FluidSpatialDis().to(dev), FluidTempoDis(3).to(dev)
+    opts = [torch.optim.Adam(m.parameters(), lr=1e-4) for m in (G, Dt, Ds)]
+    low, high, lvel, hvel = fluid_clip(2, 1024, 8, 3, seed=3, with_vel=True, device=dev)
+    opt = Namespace(use_vel=True, in_node_feats=6, cutoff=0.025, R=0.10, w=0.5)
+    for n_iter in (12, 13):
+        out = tempo_gan_step(G, Ds, Dt, low, lvel, high, hvel, 1.0, opt, n_iter, opts[0], opts[1], opts[2],
+                             force_gate=True, amp_dtype=torch.bfloat16)
+        assert all(np.isfinite(v) for v in out.values())
+        assert (out["tempo_D_loss"] > 0) == (n_iter % 2 == 0)

@@ -451,3 +451,35 @@ def test_spectral_norm_multi_matches_chained_single_calls(hip):
             ref += hip.spectral_norm_bwd(g, Wsn, u, v, sigma)
             i += 1
         assert torch.allclose(dw[off:off + R_ * Cn].view(R_, Cn), ref, rtol=1e-4, atol=1e-5)
+
+
+# ------------------------------------------------------------------ fused cubic interpolation
+@pytest.mark.parametrize("B,Nq,Np,F,cutoff", [(2, 500, 700, 3, 0.12), (3, 1024, 4096, 3, 0.16), (1, 64, 40, 5, 0.5)])
+def test_cubic_interp_matches_oracle(hip, B, Nq, Np, F, cutoff):
+    rng = np.random.default_rng(Nq + Np)
+    pos = rng.uniform(-0.3, 0.3, (B, Np, 3)).astype(np.float32)
+    field = rng.standard_normal((B, Np, F)).astype(np.float32)
+    query = rng.uniform(-0.32, 0.32, (B, Nq, 3)).astype(np.float32)
+    query[0, :5] = 999.0                        # dummies: no hit
+    query[0, 5:30] = pos[0, :25]                # exact coincidences
+    plain, pad, hits = hip.cubic_interp(dev(query), dev(pos), dev(field), cutoff)
+    rp, rpad, rh = R.cubic_interp(query, pos, field, cutoff)
+    assert np.array_equal(hits.cpu().numpy(), rh)                         # same neighbour sets
+    assert rh.max() == 32 or Np < 32
+    for got, want in ((plain, rp), (pad, rpad)):
+        assert np.abs(got.cpu().numpy() - want).max() <= 1e-5 * max(1.0, np.abs(want).max())
+    assert np.all(plain.cpu().numpy()[0, :5] == 0.0)
+
+
+def test_cubic_interpolation_selects_padding_per_cloud(hip):
+    import tpgan_amd.ops as ops
+    rng = np.random.default_rng(5)
+    pos = rng.uniform(-0.3, 0.3, (2, 600, 3)).astype(np.float32)
+    field = rng.standard_normal((2, 600, 3)).astype(np.float32)
+    query = rng.uniform(-0.3, 0.3, (2, 256, 3)).astype(np.float32)
+    query[1, 0] = 999.0                         # cloud 1 gets the reference's padding edges, cloud 0 does not
+    out = ops.cubic_interpolation(dev(query), dev(field), dev(pos), 0.1).cpu().numpy()
+    plain, pad, hits = (t.cpu().numpy() for t in hip.cubic_interp(dev(query), dev(pos), dev(field), 0.1))
+    assert np.array_equal(out[0], plain[0])
+    assert np.array_equal(out[1], np.where((hits[1] < 32)[:, None], pad[1], plain[1]))
+    assert (hits[1] < 32).any() and not np.array_equal(pad[1], plain[1])

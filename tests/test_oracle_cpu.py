@@ -183,3 +183,33 @@ def test_three_nn_and_interpolate():
         for c in range(4):
             np.add.at(ref[b, c], idx[b].reshape(-1), (g[b, c][:, None] * w[b]).reshape(-1))
     assert np.allclose(gf, ref, atol=1e-5)
+
+
+# ------------------------------------------------------------------ cubic interpolation (--use_vel)
+@pytest.mark.parametrize("case", ["dense", "with_far_queries", "coincident"])
+def test_cubic_interpolation_matches_the_reference_algorithm(case, oracle_cpu):
+    """ops.cubic_interpolation (one fused search-and-sum per batch + the padding selection) against
+    the reference's algorithm written out as an edge list (oracle/bruteforce.py): FRNN-32, unique,
+    FRNN again, kNN-4 padding multigraph, DGL-style scatter sums.  PARITY UNPINNED against DGL itself
+    (not installable here); the edge-list statement follows gcn_lib/interpolation.py line by line."""
+    import torch
+    import tpgan_amd.ops as ops
+    rng = np.random.default_rng({"dense": 0, "with_far_queries": 1, "coincident": 2}[case])
+    B, Np, Nq, F, cutoff = 2, 300, 96, 3, 0.16
+    pos = rng.uniform(-0.3, 0.3, (B, Np, 3)).astype(np.float32)
+    field = rng.standard_normal((B, Np, F)).astype(np.float32)
+    query = rng.uniform(-0.3, 0.3, (B, Nq, 3)).astype(np.float32)
+    if case == "with_far_queries":            # 999-dummies of a masked prediction: no hit -> padding active
+        query[0, :7] = 999.0
+        query[0, 7:20] = rng.uniform(0.36, 0.4, (13, 3))          # few hits
+    if case == "coincident":
+        query[:, :40] = pos[:, :40]                                # d = 0 exactly
+    got = ops.cubic_interpolation(torch.from_numpy(query), torch.from_numpy(field), torch.from_numpy(pos), cutoff).numpy()
+    for b in range(B):
+        want = BF.cubic_interpolation(query[b], field[b], pos[b], cutoff)
+        assert np.abs(got[b] - want).max() <= 1e-5 * max(1.0, np.abs(want).max()), (case, b)
+    if case == "with_far_queries":
+        assert np.all(got[0, :7] == 0.0)                           # no neighbours: 0 / (0 + 1e-6)
+    # the per-sample 2-D signature of the reference
+    one = ops.cubic_interpolation(torch.from_numpy(query[1]), torch.from_numpy(field[1]), torch.from_numpy(pos[1]), cutoff)
+    assert np.array_equal(one.numpy(), got[1])
