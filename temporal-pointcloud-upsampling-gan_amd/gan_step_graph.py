@@ -357,7 +357,10 @@ class GraphedFluidStep:
             g.replay()
             if reduce_module is not None:
                 self.sync.average_grads(reduce_module)
-        out = torch.cat([self.report, self.viol]).cpu().tolist()        # the step's one host sync
+        # multi-GPU: the decision to leave the graph path must be COLLECTIVE -- the eager step issues
+        # other all-reduces than the replay, so every rank falls back as soon as one rank has to
+        viol = self.sync.gate_value(self.viol) if self.sync.world_size > 1 else self.viol
+        out = torch.cat([self.report, viol.reshape(1)]).cpu().tolist()   # the step's one host sync
         if out[6] != 0.0:
             # not the static regime: put everything back and take the general path with the same draws
             for d, t in zip(self._snap, self._state):
