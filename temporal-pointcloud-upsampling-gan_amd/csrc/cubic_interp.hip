@@ -17,6 +17,7 @@
 //
 // One wave per query, same search as knn.hip (D = 3, K = 32, radius); the 32 best keys end up
 // one per lane, so weights, multiplicities and the F+1 sums are a handful of wave reductions.
+#include "knn_select.hpp"
 #include "tpg_common.hpp"
 
 namespace {
@@ -43,8 +44,10 @@ __global__ __launch_bounds__(CI_WAVES * 64) void cubic_interp_kernel(
     const float *__restrict__ query, const float *__restrict__ pos, const float *__restrict__ field, int Nq,
     int Np, int F, float cutoff, float r2, float coeff, float *__restrict__ out_plain,
     float *__restrict__ out_pad, int32_t *__restrict__ hits) {
+    __shared__ tpg_u64 ci_slots[CI_WAVES * 64];
     const int lane = threadIdx.x & 63;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    tpg_u64 *slot = ci_slots + wave * 64;
     const int b = blockIdx.y;
     const int i = blockIdx.x * CI_WAVES + wave;
     if (i >= Nq) return;
@@ -60,18 +63,7 @@ __global__ __launch_bounds__(CI_WAVES * 64) void cubic_interp_kernel(
             const float d = tpg_sq3(qx, qy, qz, cb[(size_t)j * 3], cb[(size_t)j * 3 + 1], cb[(size_t)j * 3 + 2]);
             if (d < r2) key = ((tpg_u64)__float_as_uint(d) << 32) | (unsigned)j;
         }
-        tpg_u64 mask = __ballot(key < thr);
-        while (mask) {
-            const int src = __builtin_amdgcn_readfirstlane(__builtin_ctzll(mask));
-            mask &= mask - 1;
-            const tpg_u64 x = tpg_readlane_u64(key, src);
-            if (x < thr) {
-                const int p = __popcll(__ballot(best < x));
-                const tpg_u64 up = __shfl_up(best, 1);
-                best = lane < p ? best : (lane == p ? x : up);
-                thr = tpg_readlane_u64(best, CI_K - 1);
-            }
-        }
+        tpg_knn_merge(best, thr, key, CI_K, lane, slot);
     }
     const bool has = lane < CI_K && best != INF;
     const int nh = __popcll(__ballot(has));

@@ -21,6 +21,7 @@
 //     minimum, one DPP wave reduction at the end.
 // The kernel is HBM/L2-light (each cloud is a few KB..1.5 MB and stays in L2);
 // its bound is VALU issue + cross-lane latency, see DESIGN.md.
+#include "knn_select.hpp"
 #include "tpg_common.hpp"
 
 namespace {
@@ -70,10 +71,12 @@ __global__ __launch_bounds__(KNN_WAVES * 64) void knn_kernel(
     const int64_t *__restrict__ len1, const int64_t *__restrict__ len2, int B, int P1, int P2,
     int D, int K, float r2, float *__restrict__ dist, int64_t *__restrict__ idx) {
     extern __shared__ __attribute__((aligned(16))) float knn_q[];  // [KNN_WAVES][Dpad]
+    __shared__ tpg_u64 knn_slots[KNN_WAVES * 64];                   // rank-merge scratch, one slot row per wave
     const int lane = threadIdx.x & 63;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int Dpad = (D + 3) & ~3;
     float *qs = knn_q + wave * Dpad;
+    tpg_u64 *slot = knn_slots + wave * 64;
 
     const int b = blockIdx.y;
     const int i = blockIdx.x * KNN_WAVES + wave;
@@ -128,18 +131,7 @@ __global__ __launch_bounds__(KNN_WAVES * 64) void knn_kernel(
             const float d = knn_dist<D_T>(qs, cbase + (size_t)j * D, D);
             if (!RADIUS || d < r2) key = knn_pack(d, j);
         }
-        tpg_u64 mask = __ballot(key < thr);
-        while (mask) {
-            const int src = __builtin_amdgcn_readfirstlane(__builtin_ctzll(mask));
-            mask &= mask - 1;
-            const tpg_u64 x = tpg_readlane_u64(key, src);
-            if (x < thr) {  // wave-uniform: thr may have dropped since the ballot
-                const int pos = __popcll(__ballot(best < x));
-                const tpg_u64 up = __shfl_up(best, 1);
-                best = lane < pos ? best : (lane == pos ? x : up);
-                thr = tpg_readlane_u64(best, K - 1);
-            }
-        }
+        tpg_knn_merge(best, thr, key, K, lane, slot);
     }
     if (lane < K) {
         if (best == INF) { od[lane] = pad_d; oi[lane] = pad_i; }
@@ -147,6 +139,87 @@ __global__ __launch_bounds__(KNN_WAVES * 64) void knn_kernel(
             od[lane] = __uint_as_float((unsigned)(best >> 32));
             oi[lane] = (long long)(unsigned)best;
         }
+    }
+}
+
+// ---- feature-space kNN (D = 32 / 64): a wave keeps its 64 candidate rows in REGISTERS and scores
+// them against Q queries (broadcast from LDS) before moving on.  In the one-query-per-wave kernel
+// above every query re-reads the whole cloud (P2 * D * 4 B: 128 KB at D = 64), i.e. 1.6 GB of
+// L1/L2 traffic for the generator's (24, 512, 64) searches (9 TB/s: the L2 rate) -- that, not
+// the arithmetic or the list updates, was its 177 us.  Scoring Q queries per candidate tile
+// divides the traffic by Q; the Q neighbour lists stay one key per lane each (2Q VGPRs).  Same
+// keys, same total order => the same neighbours as the kernel above, bit for bit.  Q is small
+// (2-4): each wave's tiles are a chain of load -> score, and more queries per wave means fewer
+// waves to overlap those chains.
+template <int D_T, int Q, bool RADIUS>
+__global__ __launch_bounds__(KNN_WAVES * 64) void knn_tile_kernel(
+    const float *__restrict__ p1, const float *__restrict__ p2, const int64_t *__restrict__ len1,
+    const int64_t *__restrict__ len2, int P1, int P2, int K, float r2, float *__restrict__ dist,
+    int64_t *__restrict__ idx) {
+    static_assert(D_T % 4 == 0, "rows are read as float4");
+    __shared__ __attribute__((aligned(16))) float qsm[KNN_WAVES * Q * D_T];
+    __shared__ tpg_u64 knn_slots[KNN_WAVES * 64];
+    const int lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    tpg_u64 *slot = knn_slots + wave * 64;
+    const int b = blockIdx.y;
+    const int q0 = (blockIdx.x * KNN_WAVES + wave) * Q;        // this wave's first query
+    float *qs = qsm + wave * Q * D_T;
+    for (int t = lane; t < Q * D_T; t += 64) {
+        const int qq = t / D_T, d = t - qq * D_T;
+        const int i = q0 + qq;
+        qs[t] = i < P1 ? p1[((size_t)b * P1 + i) * D_T + d] : 0.0f;
+    }
+    __syncthreads();
+    const int n1 = len1 ? (int)len1[b] : P1;
+    const int n2 = len2 ? min((int)len2[b], P2) : P2;
+    const tpg_u64 INF = ~0ull;
+    tpg_u64 best[Q], thr[Q];
+#pragma unroll
+    for (int qq = 0; qq < Q; ++qq) { best[qq] = INF; thr[qq] = INF; }
+    const float *cbase = p2 + (size_t)b * P2 * D_T;
+    for (int base = 0; base < n2; base += 64) {
+        const int j = base + lane;
+        float4 row[D_T / 4];
+        if (j < n2) {
+            const float4 *c4 = reinterpret_cast<const float4 *>(cbase + (size_t)j * D_T);
+#pragma unroll
+            for (int d = 0; d < D_T / 4; ++d) row[d] = c4[d];
+        } else {
+#pragma unroll
+            for (int d = 0; d < D_T / 4; ++d) row[d] = make_float4(0.f, 0.f, 0.f, 0.f);
+        }
+#pragma unroll
+        for (int qq = 0; qq < Q; ++qq) {
+            // compiler barrier: the query rows are loop-invariant, and without it LICM hoists all
+            // Q*D of them out of the tile loop into registers (512 VGPRs + scratch); with it each
+            // query is re-read from LDS (broadcast ds_read_b128) right before it is used
+            asm volatile("" ::: "memory");
+            const float4 *q4 = reinterpret_cast<const float4 *>(qs + qq * D_T);
+            float acc = 0.0f;
+#pragma unroll
+            for (int d = 0; d < D_T / 4; ++d) {
+                const float4 qv = q4[d];
+                float t;
+                t = qv.x - row[d].x; acc = acc + t * t;
+                t = qv.y - row[d].y; acc = acc + t * t;
+                t = qv.z - row[d].z; acc = acc + t * t;
+                t = qv.w - row[d].w; acc = acc + t * t;
+            }
+            tpg_u64 key = INF;
+            if (j < n2 && (!RADIUS || acc < r2)) key = knn_pack(acc, j);
+            tpg_knn_merge(best[qq], thr[qq], key, K, lane, slot);
+        }
+    }
+    const float pad_d = RADIUS ? -1.0f : 0.0f;
+    const long long pad_i = RADIUS ? -1 : 0;
+#pragma unroll
+    for (int qq = 0; qq < Q; ++qq) {
+        const int i = q0 + qq;
+        if (i >= P1 || lane >= K) continue;
+        const size_t o = ((size_t)b * P1 + i) * K + lane;
+        if (i >= n1 || n2 <= 0 || best[qq] == INF) { dist[o] = pad_d; idx[o] = pad_i; }
+        else { dist[o] = __uint_as_float((unsigned)(best[qq] >> 32)); idx[o] = (long long)(unsigned)best[qq]; }
     }
 }
 
@@ -161,6 +234,32 @@ int knn_launch(const float *p1, const float *p2, const int64_t *len1, const int6
     if (smem > 64 * 1024) return TPG_ERR_UNSUPPORTED;
     // the vector path also needs 16-B aligned rows: D % 4 == 0 and aligned bases
     const bool al = ((reinterpret_cast<uintptr_t>(p1) | reinterpret_cast<uintptr_t>(p2)) & 15) == 0;
+    // feature-space searches with several neighbours: the query-tiled kernel
+#ifndef TPG_KNN_NO_TILE
+    // feature-space searches: the query-tiled kernel.  Measured on (24,512,D) clouds
+    // (tools/tune_knn.py): D = 64: Q = 4 is 2.1x faster than one query per wave (177 -> 85 us),
+    // D = 32: Q = 2 is 1.3-1.7x faster up to K ~ 20; larger Q serialises too much work per wave.
+#ifdef TPG_KNN_TILE_Q            // sweep builds force one Q
+    constexpr int Q64 = TPG_KNN_TILE_Q, Q32 = TPG_KNN_TILE_Q;
+    const bool tile32 = true;
+#else
+    constexpr int Q64 = 4, Q32 = 2;
+    const bool tile32 = K <= 24;
+#endif
+    if (al && K > 1 && ((D == 64 && P1 >= KNN_WAVES * Q64) || (D == 32 && tile32 && P1 >= KNN_WAVES * Q32))) {
+        if (D == 32) {
+            const dim3 tg((unsigned)((P1 + KNN_WAVES * Q32 - 1) / (KNN_WAVES * Q32)), (unsigned)B);
+            hipLaunchKernelGGL((knn_tile_kernel<32, Q32, RADIUS>), tg, block, 0, st, p1, p2, len1, len2, P1, P2, K, r2,
+                               dist, idx);
+        } else {
+            const dim3 tg((unsigned)((P1 + KNN_WAVES * Q64 - 1) / (KNN_WAVES * Q64)), (unsigned)B);
+            hipLaunchKernelGGL((knn_tile_kernel<64, Q64, RADIUS>), tg, block, 0, st, p1, p2, len1, len2, P1, P2, K, r2,
+                               dist, idx);
+        }
+        TPG_RETURN_IF_LAUNCH_FAILED();
+        return TPG_OK;
+    }
+#endif
 #define TPG_KNN_GO(DT) \
     hipLaunchKernelGGL((knn_kernel<DT, RADIUS>), grid, block, smem, st, p1, p2, len1, len2, B, P1, \
                        P2, D, K, r2, dist, idx)

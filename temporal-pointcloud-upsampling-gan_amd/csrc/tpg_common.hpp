@@ -43,6 +43,10 @@ __device__ __forceinline__ tpg_u64 tpg_dpp_u64(tpg_u64 v) {
     return ((tpg_u64)hi << 32) | lo;
 }
 
+// lane l receives lane l-1's value (lane 0: unspecified / its own): one DPP move per dword
+// (wave_shr:1) instead of a ds_bpermute round trip through the LDS crossbar
+__device__ __forceinline__ tpg_u64 tpg_wave_shr1_u64(tpg_u64 v) { return tpg_dpp_u64<0x138>(v); }
+
 __device__ __forceinline__ tpg_u64 tpg_readlane_u64(tpg_u64 v, int lane_uniform) {
     const unsigned lo = (unsigned)__builtin_amdgcn_readlane((int)(unsigned)v, lane_uniform);
     const unsigned hi = (unsigned)__builtin_amdgcn_readlane((int)(unsigned)(v >> 32), lane_uniform);

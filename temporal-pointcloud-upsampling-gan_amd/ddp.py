@@ -62,11 +62,12 @@ class GradSync:
         flat = torch.cat([g.reshape(-1) for g in grads])
         dist.all_reduce(flat, op=dist.ReduceOp.SUM, group=self.group)
         flat.div_(self.world_size)
-        off = 0
+        views, off = [], 0
         for g in grads:
             n = g.numel()
-            g.copy_(flat[off:off + n].view_as(g))
+            views.append(flat[off:off + n].view_as(g))
             off += n
+        torch._foreach_copy_(grads, views)          # one multi-tensor launch, not one copy per gradient
 
     def broadcast_state(self, *modules, src=0):
         """Make parameters AND buffers (BN stats, spectral-norm u/v) identical at start."""
