@@ -36,7 +36,7 @@ import torch
 
 from .gan_step import _frozen, _autocast, _set_dummy_check, _NoSync, get_rotation_matrix, tempo_gan_step
 from .losses import tpugan_sr_loss
-from .set_abstraction import run_index_plan
+from .set_abstraction import _plan_tensors, run_index_plan
 
 
 def _state_tensors(modules, optims):
@@ -126,6 +126,7 @@ class GraphedFluidStep:
         self.report = torch.zeros(6, device=dev)
         self.viol = torch.zeros(1, device=dev)
         self.side = torch.cuda.Stream(dev)
+        self.branch = torch.cuda.Stream(dev)       # the spatial discriminator's update (single-GPU form)
         self.use_plans = True
         self._keep = {}
         self._graphs = None
@@ -240,6 +241,48 @@ class GraphedFluidStep:
                                        k["cd"].reshape(()), k["ml"].reshape(()),
                                        k["spatial_loss"].reshape(()), k["spatial_dis_loss"].reshape(())]).float())
 
+    def _body_concurrent(self, update_D):
+        """The whole step as ONE body with the two discriminator updates side by side.
+
+        After the generator's segment the temporal and the spatial update are independent
+        (different networks, different optimizers; both read only the detached fakes and the
+        real clouds), and each is a chain of many short kernels with ~5 us of dependent-launch
+        latency between them.  The spatial update therefore runs on its own stream: inside the
+        captured graph the two chains become parallel branches that fill each other's gaps.
+        (Single-GPU form; with gradient all-reduces between the segments the step stays
+        sequential, `_segments`.)"""
+        self._seg_generator(update_D)
+        self.og.step()
+        k, lab = self._keep, self.lab
+        if not update_D:
+            k["tempo_dis_loss"] = torch.zeros((), device=self.dev)
+            k["spatial_dis_loss"] = torch.zeros((), device=self.dev)
+        else:
+            main = torch.cuda.current_stream(self.dev)
+            self.branch.wait_stream(main)
+            with torch.cuda.stream(self.branch):
+                for t in [k["fake_s"], k["true_s"], lab] + _plan_tensors(k["plan_s"]):
+                    t.record_stream(self.branch)
+                with _autocast(self.amp, self.dev):
+                    fake, true = self.Ds.forward_passes([k["fake_s"], k["true_s"]], plan=k["plan_s"])
+                loss_s = (0.5 * ((true.float() - lab[0]) ** 2 + (fake.float() - lab[1]) ** 2)).mean()
+                self.os.zero_grad(set_to_none=True)
+                loss_s.backward()
+                self.os.step()
+                k["spatial_dis_loss"] = loss_s.detach()
+                k["spatial_dis_loss"].record_stream(main)
+            with _autocast(self.amp, self.dev):
+                fake, true = self.Dt.forward_passes([k["fakes"], k["trues"]], self.opt.R, plan=k["plan_t"])
+            loss_t = (0.5 * ((true.float() - lab[0]) ** 2 + (fake.float() - lab[1]) ** 2)).mean()
+            self.ot.zero_grad(set_to_none=True)
+            loss_t.backward()
+            self.ot.step()
+            k["tempo_dis_loss"] = loss_t.detach()
+            main.wait_stream(self.branch)
+        self.report.copy_(torch.stack([k["tempo_loss"].reshape(()), k["tempo_dis_loss"].reshape(()),
+                                       k["cd"].reshape(()), k["ml"].reshape(()),
+                                       k["spatial_loss"].reshape(()), k["spatial_dis_loss"].reshape(())]).float())
+
     def _segments(self, update_D):
         return [("G", lambda: self._seg_generator(update_D), self.G),
                 ("Dt", lambda: self._seg_tempo(update_D), self.Dt if update_D else None),
@@ -247,6 +290,9 @@ class GraphedFluidStep:
                 ("end", lambda: self._seg_finish(update_D), None)]
 
     def _run_eager(self, update_D):
+        if not self.segmented:
+            self._body_concurrent(update_D)
+            return
         for _, fn, reduce_module in self._segments(update_D):
             fn()
             if reduce_module is not None:
@@ -302,7 +348,7 @@ class GraphedFluidStep:
             graphs, pool = [], None
             segs = self._segments(update_D)
             if not self.segmented:
-                segs = [("all", lambda segs=segs: [fn() for _, fn, _ in segs], None)]
+                segs = [("all", lambda update_D=update_D: self._body_concurrent(update_D), None)]
             for name, fn, reduce_module in segs:
                 g = torch.cuda.CUDAGraph()
                 with torch.cuda.graph(g, pool=pool):
@@ -312,6 +358,7 @@ class GraphedFluidStep:
                         # leave the capture joinable: an unjoined side stream turns the original
                         # error into "capturing stream has unjoined work" and poisons the stream
                         torch.cuda.current_stream(self.dev).wait_stream(self.side)
+                        torch.cuda.current_stream(self.dev).wait_stream(self.branch)
                         raise
                 pool = g.pool()
                 graphs.append((g, reduce_module))
