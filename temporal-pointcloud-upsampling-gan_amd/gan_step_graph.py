@@ -126,7 +126,8 @@ class GraphedFluidStep:
         self.report = torch.zeros(6, device=dev)
         self.viol = torch.zeros(1, device=dev)
         self.side = torch.cuda.Stream(dev)
-        self.branch = torch.cuda.Stream(dev)       # the spatial discriminator's update (single-GPU form)
+        self.branch = torch.cuda.Stream(dev)       # the discriminators' updates (single-GPU form)
+        self.branch2 = torch.cuda.Stream(dev)
         self.use_plans = True
         self._keep = {}
         self._graphs = None
@@ -139,7 +140,7 @@ class GraphedFluidStep:
             return None, (lambda: None)
         return run_index_plan(make, self.side)
 
-    def _seg_generator(self, update_D):
+    def _seg_generator(self, update_D, defer_backward=False):
         G, Ds, Dt, opt, k = self.G, self.Ds, self.Dt, self.opt, self._keep
         low, high, lab = self.low, self.high, self.lab
         others = [0] + list(range(2, self.T))
@@ -200,10 +201,12 @@ class GraphedFluidStep:
             fake = Dt.forward_passes([fake_t_in], opt.R, plan=plan_ft)[0]
             tempo_loss = (0.5 * (fake.float() - lab[3]) ** 2).mean()
         sr_loss = tempo_loss + spatial_loss + opt.w * position_loss
-        self.og.zero_grad(set_to_none=True)
-        sr_loss.backward()
         k.update(tempo_loss=tempo_loss.detach(), spatial_loss=spatial_loss.detach(), cd=cd.detach(), ml=ml.detach())
         self.viol.copy_(viol.float().reshape(1))
+        if defer_backward:
+            return sr_loss
+        self.og.zero_grad(set_to_none=True)
+        sr_loss.backward()
         # every side-stream branch rejoins before this segment ends (required inside a capture)
         torch.cuda.current_stream(self.dev).wait_stream(self.side)
 
@@ -242,24 +245,26 @@ class GraphedFluidStep:
                                        k["spatial_loss"].reshape(()), k["spatial_dis_loss"].reshape(())]).float())
 
     def _body_concurrent(self, update_D):
-        """The whole step as ONE body with the two discriminator updates side by side.
+        """The whole step as ONE body whose three backward-heavy parts run side by side.
 
-        After the generator's segment the temporal and the spatial update are independent
-        (different networks, different optimizers; both read only the detached fakes and the
-        real clouds), and each is a chain of many short kernels with ~5 us of dependent-launch
-        latency between them.  The spatial update therefore runs on its own stream: inside the
-        captured graph the two chains become parallel branches that fill each other's gaps.
+        Once the generator's forward has produced the fake frames, three things are independent:
+        the generator's own backward (through the frozen discriminators), the temporal and the
+        spatial discriminator update (they read only the detached fakes and the real clouds).
+        Each is a chain of many short kernels with ~5 us of dependent-launch latency between
+        them, so the two discriminator updates run on their own streams: inside the captured
+        graph the three chains are parallel branches that fill each other's gaps.  Order kept:
+        the updates' forwards come after the generator step's discriminator forwards (spectral
+        norm iterations, BatchNorm running statistics), and the discriminators' optimizer steps
+        wait for the generator's backward, which still reads their parameters.
         (Single-GPU form; with gradient all-reduces between the segments the step stays
         sequential, `_segments`.)"""
-        self._seg_generator(update_D)
-        self.og.step()
+        sr_loss = self._seg_generator(update_D, defer_backward=True)
         k, lab = self._keep, self.lab
-        if not update_D:
-            k["tempo_dis_loss"] = torch.zeros((), device=self.dev)
-            k["spatial_dis_loss"] = torch.zeros((), device=self.dev)
-        else:
-            main = torch.cuda.current_stream(self.dev)
-            self.branch.wait_stream(main)
+        main = torch.cuda.current_stream(self.dev)
+        if update_D:
+            for br in (self.branch, self.branch2):
+                br.wait_stream(main)
+                br.wait_stream(self.side)          # the index plans of the updates
             with torch.cuda.stream(self.branch):
                 for t in [k["fake_s"], k["true_s"], lab] + _plan_tensors(k["plan_s"]):
                     t.record_stream(self.branch)
@@ -268,17 +273,30 @@ class GraphedFluidStep:
                 loss_s = (0.5 * ((true.float() - lab[0]) ** 2 + (fake.float() - lab[1]) ** 2)).mean()
                 self.os.zero_grad(set_to_none=True)
                 loss_s.backward()
-                self.os.step()
                 k["spatial_dis_loss"] = loss_s.detach()
                 k["spatial_dis_loss"].record_stream(main)
-            with _autocast(self.amp, self.dev):
-                fake, true = self.Dt.forward_passes([k["fakes"], k["trues"]], self.opt.R, plan=k["plan_t"])
-            loss_t = (0.5 * ((true.float() - lab[0]) ** 2 + (fake.float() - lab[1]) ** 2)).mean()
-            self.ot.zero_grad(set_to_none=True)
-            loss_t.backward()
-            self.ot.step()
-            k["tempo_dis_loss"] = loss_t.detach()
+            with torch.cuda.stream(self.branch2):
+                for t in k["fakes"] + k["trues"] + [lab] + _plan_tensors(k["plan_t"]):
+                    t.record_stream(self.branch2)
+                with _autocast(self.amp, self.dev):
+                    fake, true = self.Dt.forward_passes([k["fakes"], k["trues"]], self.opt.R, plan=k["plan_t"])
+                loss_t = (0.5 * ((true.float() - lab[0]) ** 2 + (fake.float() - lab[1]) ** 2)).mean()
+                self.ot.zero_grad(set_to_none=True)
+                loss_t.backward()
+                k["tempo_dis_loss"] = loss_t.detach()
+                k["tempo_dis_loss"].record_stream(main)
+        else:
+            k["tempo_dis_loss"] = torch.zeros((), device=self.dev)
+            k["spatial_dis_loss"] = torch.zeros((), device=self.dev)
+        self.og.zero_grad(set_to_none=True)
+        sr_loss.backward()
+        self.og.step()
+        main.wait_stream(self.side)
+        if update_D:
             main.wait_stream(self.branch)
+            main.wait_stream(self.branch2)
+            self.ot.step()
+            self.os.step()
         self.report.copy_(torch.stack([k["tempo_loss"].reshape(()), k["tempo_dis_loss"].reshape(()),
                                        k["cd"].reshape(()), k["ml"].reshape(()),
                                        k["spatial_loss"].reshape(()), k["spatial_dis_loss"].reshape(())]).float())
@@ -359,6 +377,7 @@ class GraphedFluidStep:
                         # error into "capturing stream has unjoined work" and poisons the stream
                         torch.cuda.current_stream(self.dev).wait_stream(self.side)
                         torch.cuda.current_stream(self.dev).wait_stream(self.branch)
+                        torch.cuda.current_stream(self.dev).wait_stream(self.branch2)
                         raise
                 pool = g.pool()
                 graphs.append((g, reduce_module))
