@@ -53,10 +53,12 @@ class GradSync:
         return v / self.world_size
 
     def average_grads(self, module):
-        """Average every existing .grad of `module` with one flat all-reduce."""
+        """Average every existing .grad of `module` (or of a list of modules) with ONE flat
+        all-reduce."""
         if self.world_size == 1:
             return
-        grads = [p.grad for p in module.parameters() if p.grad is not None]
+        modules = module if isinstance(module, (list, tuple)) else [module]
+        grads = [p.grad for m in modules for p in m.parameters() if p.grad is not None]
         if not grads:
             return
         flat = torch.cat([g.reshape(-1) for g in grads])

@@ -26,10 +26,17 @@ as soon as its input clouds exist (the real clouds at the very start of the step
 right before use: inside the captured graph the chains become parallel branches that overlap
 with the generator and discriminator GEMMs.
 
-Multi-GPU: with `sync.world_size > 1` the step is captured as four graphs and the three flat
-gradient all-reduces run eagerly between them (RCCL calls are kept out of capture).
+Concurrency inside the step: after the generator's forward, its backward and the two
+discriminator updates are independent chains of short kernels; they run on three streams and
+become parallel branches of the captured graph (`_phase_grads`); all optimizer steps follow
+(`_phase_apply`).
+
+Multi-GPU: with `sync.world_size > 1` the step is captured as two graphs (`_phase_grads`,
+`_phase_apply`) and ONE flat gradient all-reduce over the three networks runs eagerly between
+them (RCCL calls are kept out of capture).
 """
 import contextlib
+import os
 
 import numpy as np
 import torch
@@ -96,6 +103,8 @@ class GraphedFluidStep:
                 raise ValueError("graph capture needs optimizers built with capturable=True")
         self.opt, self.fd, self.amp = opt, furthest_distance, amp_dtype
         self.sync = sync or _NoSync()
+        if segmented is None and os.environ.get("TPGAN_GRAPH_SEGMENTED"):     # measure the multi-GPU form on one GPU
+            segmented = os.environ["TPGAN_GRAPH_SEGMENTED"] != "0"
         self.segmented = (self.sync.world_size > 1) if segmented is None else segmented
         dev = lowres_pos_lst[0].device
         self.dev, self.T, self.B = dev, len(highres_pos_lst), lowres_pos_lst[0].shape[0]
@@ -210,42 +219,8 @@ class GraphedFluidStep:
         # every side-stream branch rejoins before this segment ends (required inside a capture)
         torch.cuda.current_stream(self.dev).wait_stream(self.side)
 
-    def _seg_tempo(self, update_D):
-        self.og.step()
-        k, lab = self._keep, self.lab
-        if not update_D:
-            k["tempo_dis_loss"] = torch.zeros((), device=self.dev)
-            return
-        with _autocast(self.amp, self.dev):
-            fake, true = self.Dt.forward_passes([k["fakes"], k["trues"]], self.opt.R, plan=k["plan_t"])
-        loss = (0.5 * ((true.float() - lab[0]) ** 2 + (fake.float() - lab[1]) ** 2)).mean()
-        self.ot.zero_grad(set_to_none=True)
-        loss.backward()
-        k["tempo_dis_loss"] = loss.detach()
-
-    def _seg_spatial(self, update_D):
-        k, lab = self._keep, self.lab
-        if not update_D:
-            k["spatial_dis_loss"] = torch.zeros((), device=self.dev)
-            return
-        self.ot.step()
-        with _autocast(self.amp, self.dev):
-            fake, true = self.Ds.forward_passes([k["fake_s"], k["true_s"]], plan=k["plan_s"])
-        loss = (0.5 * ((true.float() - lab[0]) ** 2 + (fake.float() - lab[1]) ** 2)).mean()
-        self.os.zero_grad(set_to_none=True)
-        loss.backward()
-        k["spatial_dis_loss"] = loss.detach()
-
-    def _seg_finish(self, update_D):
-        if update_D:
-            self.os.step()
-        k = self._keep
-        self.report.copy_(torch.stack([k["tempo_loss"].reshape(()), k["tempo_dis_loss"].reshape(()),
-                                       k["cd"].reshape(()), k["ml"].reshape(()),
-                                       k["spatial_loss"].reshape(()), k["spatial_dis_loss"].reshape(())]).float())
-
-    def _body_concurrent(self, update_D):
-        """The whole step as ONE body whose three backward-heavy parts run side by side.
+    def _phase_grads(self, update_D):
+        """Forward and backward of the whole step: three backward-heavy parts side by side.
 
         Once the generator's forward has produced the fake frames, three things are independent:
         the generator's own backward (through the frozen discriminators), the temporal and the
@@ -254,10 +229,9 @@ class GraphedFluidStep:
         them, so the two discriminator updates run on their own streams: inside the captured
         graph the three chains are parallel branches that fill each other's gaps.  Order kept:
         the updates' forwards come after the generator step's discriminator forwards (spectral
-        norm iterations, BatchNorm running statistics), and the discriminators' optimizer steps
-        wait for the generator's backward, which still reads their parameters.
-        (Single-GPU form; with gradient all-reduces between the segments the step stays
-        sequential, `_segments`.)"""
+        norm iterations, BatchNorm running statistics), and every optimizer step comes in
+        `_phase_apply`, after the generator's backward -- which still reads the discriminators'
+        parameters -- has finished."""
         sr_loss = self._seg_generator(update_D, defer_backward=True)
         k, lab = self._keep, self.lab
         main = torch.cuda.current_stream(self.dev)
@@ -290,31 +264,30 @@ class GraphedFluidStep:
             k["spatial_dis_loss"] = torch.zeros((), device=self.dev)
         self.og.zero_grad(set_to_none=True)
         sr_loss.backward()
-        self.og.step()
-        main.wait_stream(self.side)
+        main.wait_stream(self.side)                # every branch rejoins (required inside a capture)
         if update_D:
             main.wait_stream(self.branch)
             main.wait_stream(self.branch2)
+
+    def _phase_apply(self, update_D):
+        """The three optimizer steps and the loss report."""
+        self.og.step()
+        if update_D:
             self.ot.step()
             self.os.step()
+        k = self._keep
         self.report.copy_(torch.stack([k["tempo_loss"].reshape(()), k["tempo_dis_loss"].reshape(()),
                                        k["cd"].reshape(()), k["ml"].reshape(()),
                                        k["spatial_loss"].reshape(()), k["spatial_dis_loss"].reshape(())]).float())
 
-    def _segments(self, update_D):
-        return [("G", lambda: self._seg_generator(update_D), self.G),
-                ("Dt", lambda: self._seg_tempo(update_D), self.Dt if update_D else None),
-                ("Ds", lambda: self._seg_spatial(update_D), self.Ds if update_D else None),
-                ("end", lambda: self._seg_finish(update_D), None)]
+    def _reduced(self, update_D):
+        """Networks whose gradients exist after `_phase_grads` (for the multi-GPU all-reduce)."""
+        return [self.G, self.Dt, self.Ds] if update_D else [self.G]
 
     def _run_eager(self, update_D):
-        if not self.segmented:
-            self._body_concurrent(update_D)
-            return
-        for _, fn, reduce_module in self._segments(update_D):
-            fn()
-            if reduce_module is not None:
-                self.sync.average_grads(reduce_module)
+        self._phase_grads(update_D)
+        self.sync.average_grads(self._reduced(update_D))       # no-op on one GPU
+        self._phase_apply(update_D)
 
     # ------------------------------------------------------------------ capture
     def _load(self, low, high):
@@ -364,9 +337,11 @@ class GraphedFluidStep:
         self._graphs = {}
         for update_D in (True, False):
             graphs, pool = [], None
-            segs = self._segments(update_D)
-            if not self.segmented:
-                segs = [("all", lambda update_D=update_D: self._body_concurrent(update_D), None)]
+            if self.segmented:      # multi-GPU: the gradient all-reduce runs eagerly between two graphs
+                segs = [("grads", lambda u=update_D: self._phase_grads(u), self._reduced(update_D)),
+                        ("apply", lambda u=update_D: self._phase_apply(u), None)]
+            else:
+                segs = [("all", lambda u=update_D: (self._phase_grads(u), self._phase_apply(u)), None)]
             for name, fn, reduce_module in segs:
                 g = torch.cuda.CUDAGraph()
                 with torch.cuda.graph(g, pool=pool):
