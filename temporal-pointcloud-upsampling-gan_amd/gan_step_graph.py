@@ -134,7 +134,10 @@ class GraphedFluidStep:
         self._dev_f.copy_(self._host_f)
         self.report = torch.zeros(6, device=dev)
         self.viol = torch.zeros(1, device=dev)
-        self.side = torch.cuda.Stream(dev)
+        # index-plan streams: [0] temporal-D clouds, [1] spatial-D clouds (real at the start of the
+        # step, fake as soon as the generator's forward is done: FIFO order = data dependency of
+        # merge_plans), [2] / [3] the generator step's own spatial / temporal forward
+        self.sides = [torch.cuda.Stream(dev) for _ in range(2)]
         self.branch = torch.cuda.Stream(dev)       # the discriminators' updates (single-GPU form)
         self.branch2 = torch.cuda.Stream(dev)
         self.use_plans = True
@@ -143,11 +146,16 @@ class GraphedFluidStep:
         self._capture(lowres_pos_lst, highres_pos_lst, warmup)
 
     # ------------------------------------------------------------------ step body (capturable)
-    def _plan(self, make):
+    def _plan(self, make, which):
         """(plan, join) for a discriminator forward; inline (plan None) when plans are disabled."""
         if not self.use_plans:
             return None, (lambda: None)
-        return run_index_plan(make, self.side)
+        return run_index_plan(make, self.sides[which])
+
+    def _join_sides(self, stream=None):
+        stream = stream or torch.cuda.current_stream(self.dev)
+        for sd in self.sides:
+            stream.wait_stream(sd)
 
     def _seg_generator(self, update_D, defer_backward=False):
         G, Ds, Dt, opt, k = self.G, self.Ds, self.Dt, self.opt, self._keep
@@ -157,14 +165,15 @@ class GraphedFluidStep:
         _set_dummy_check(Dt, False)
         if update_D:
             # the real clouds exist already: their (rotated) copies and index plans start now
-            def real_side():
+            def real_t():
                 trues = [torch.matmul(h, self.rot_true_t[f]) for f, h in enumerate(high)]
+                return trues, (Dt.index_plan(trues, opt.R) if self.use_plans else None)
+
+            def real_s():
                 true_s = torch.bmm(high[1], self.rot_true_s)
-                if not self.use_plans:
-                    return trues, true_s, None, None
-                return trues, true_s, Dt.index_plan(trues, opt.R), Ds.index_plan(true_s)
-            (k["trues"], k["true_s"], k["plan_true_t"], k["plan_true_s"]), k["join_real"] = \
-                run_index_plan(real_side, self.side)
+                return true_s, (Ds.index_plan(true_s) if self.use_plans else None)
+            (k["trues"], k["plan_true_t"]), _ = run_index_plan(real_t, self.sides[0])
+            (k["true_s"], k["plan_true_s"]), _ = run_index_plan(real_s, self.sides[1])
         # The generator has no cross-sample coupling (no BatchNorm): its T per-frame calls
         # (train_step_final.py:116-150) are ONE call on the T*B stacked clouds, centre frame first.
         order = [1] + others
@@ -177,7 +186,7 @@ class GraphedFluidStep:
         edge, mask = edges[0], masks[0]
         pred_c, padded_c, keep_c = G.expand_pos_static(low[1], edge, mask)
         fake_s_in = padded_c.index_select(1, self.perm_c).float()
-        plan_fs, join_fs = self._plan(lambda: Ds.index_plan(fake_s_in))
+        plan_fs, join_fs = self._plan(lambda: Ds.index_plan(fake_s_in), 1)
         position_loss, cd, ml = tpugan_sr_loss(100., high[1], pred_c.float(), low[1], mask.float(),
                                                opt.cutoff / self.fd, 11)
         viol = ~(ml.reshape(()) < 0.1) | ~keep_c                   # NaN counts as a violation
@@ -191,18 +200,23 @@ class GraphedFluidStep:
                 last_padded = padded
             fake_t_in = [p.float() for p in pred_lst]
             # (merged plan of ONE pass: the frames and frame pairs still run as segments)
-            plan_ft, join_ft = self._plan(lambda: Dt.merge_plans([Dt.index_plan(fake_t_in, opt.R)]))   # overlaps D_spatial
+            plan_ft, join_ft = self._plan(lambda: Dt.merge_plans([Dt.index_plan(fake_t_in, opt.R)]), 0)   # overlaps D_spatial
             if update_D:
-                def fake_side():
+                # fake and real batch run as segments of ONE discriminator pass: one plan for both
+                # (same stream as the real plan it is merged with)
+                def fake_t():
                     fakes = [torch.matmul(p.detach(), self.rot_fake_t[f]) for f, p in enumerate(fake_t_in)]
+                    if not self.use_plans:
+                        return fakes, None
+                    return fakes, Dt.merge_plans([Dt.index_plan(fakes, opt.R), k["plan_true_t"]])
+
+                def fake_s_():
                     fake_s = torch.bmm(last_padded.detach().float(), self.rot_fake_s)
                     if not self.use_plans:
-                        return fakes, fake_s, None, None
-                    # fake and real batch run as segments of ONE discriminator pass: one plan for both
-                    return (fakes, fake_s, Dt.merge_plans([Dt.index_plan(fakes, opt.R), k["plan_true_t"]]),
-                            Ds.merge_plans([Ds.index_plan(fake_s), k["plan_true_s"]]))
-                (k["fakes"], k["fake_s"], k["plan_t"], k["plan_s"]), k["join_fake"] = \
-                    run_index_plan(fake_side, self.side)
+                        return fake_s, None
+                    return fake_s, Ds.merge_plans([Ds.index_plan(fake_s), k["plan_true_s"]])
+                (k["fakes"], k["plan_t"]), _ = run_index_plan(fake_t, self.sides[0])
+                (k["fake_s"], k["plan_s"]), _ = run_index_plan(fake_s_, self.sides[1])
             join_fs()
             fake = Ds(fake_s_in, plan=plan_fs)
             spatial_loss = (0.5 * (fake.float() - lab[2]) ** 2).mean()
@@ -217,7 +231,7 @@ class GraphedFluidStep:
         self.og.zero_grad(set_to_none=True)
         sr_loss.backward()
         # every side-stream branch rejoins before this segment ends (required inside a capture)
-        torch.cuda.current_stream(self.dev).wait_stream(self.side)
+        self._join_sides()
 
     def _phase_grads(self, update_D):
         """Forward and backward of the whole step: three backward-heavy parts side by side.
@@ -236,9 +250,10 @@ class GraphedFluidStep:
         k, lab = self._keep, self.lab
         main = torch.cuda.current_stream(self.dev)
         if update_D:
-            for br in (self.branch, self.branch2):
-                br.wait_stream(main)
-                br.wait_stream(self.side)          # the index plans of the updates
+            self.branch.wait_stream(main)
+            self.branch.wait_stream(self.sides[1])      # the spatial update's clouds and index plan
+            self.branch2.wait_stream(main)
+            self.branch2.wait_stream(self.sides[0])     # the temporal update's
             with torch.cuda.stream(self.branch):
                 for t in [k["fake_s"], k["true_s"], lab] + _plan_tensors(k["plan_s"]):
                     t.record_stream(self.branch)
@@ -264,7 +279,7 @@ class GraphedFluidStep:
             k["spatial_dis_loss"] = torch.zeros((), device=self.dev)
         self.og.zero_grad(set_to_none=True)
         sr_loss.backward()
-        main.wait_stream(self.side)                # every branch rejoins (required inside a capture)
+        self._join_sides(main)                     # every branch rejoins (required inside a capture)
         if update_D:
             main.wait_stream(self.branch)
             main.wait_stream(self.branch2)
@@ -350,7 +365,7 @@ class GraphedFluidStep:
                     except BaseException:
                         # leave the capture joinable: an unjoined side stream turns the original
                         # error into "capturing stream has unjoined work" and poisons the stream
-                        torch.cuda.current_stream(self.dev).wait_stream(self.side)
+                        self._join_sides()
                         torch.cuda.current_stream(self.dev).wait_stream(self.branch)
                         torch.cuda.current_stream(self.dev).wait_stream(self.branch2)
                         raise
