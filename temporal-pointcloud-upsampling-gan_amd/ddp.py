@@ -58,8 +58,11 @@ class GradSync:
         if self.world_size == 1:
             return
         modules = module if isinstance(module, (list, tuple)) else [module]
-        grads = [p.grad for m in modules for p in m.parameters() if p.grad is not None]
-        if not grads:
+        self.average_tensors([p.grad for m in modules for p in m.parameters() if p.grad is not None])
+
+    def average_tensors(self, grads):
+        """Average the given tensors over the ranks, in place, with ONE flat all-reduce."""
+        if self.world_size == 1 or not grads:
             return
         flat = torch.cat([g.reshape(-1) for g in grads])
         dist.all_reduce(flat, op=dist.ReduceOp.SUM, group=self.group)

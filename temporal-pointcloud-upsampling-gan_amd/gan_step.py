@@ -66,6 +66,9 @@ class _NoSync:
     def average_grads(self, module):
         pass
 
+    def average_tensors(self, grads):
+        pass
+
 
 @contextlib.contextmanager
 def _frozen(*modules):

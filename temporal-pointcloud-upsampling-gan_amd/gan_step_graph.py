@@ -359,7 +359,10 @@ class GraphedFluidStep:
                 segs = [("all", lambda u=update_D: (self._phase_grads(u), self._phase_apply(u)), None)]
             for name, fn, reduce_module in segs:
                 g = torch.cuda.CUDAGraph()
-                with torch.cuda.graph(g, pool=pool):
+                # with a process group alive, its watchdog thread polls events while we capture: only
+                # THIS thread's unsafe calls may invalidate the capture then
+                mode = {"capture_error_mode": "thread_local"} if self.sync.world_size > 1 else {}
+                with torch.cuda.graph(g, pool=pool, **mode):
                     try:
                         fn()
                     except BaseException:
@@ -370,6 +373,10 @@ class GraphedFluidStep:
                         torch.cuda.current_stream(self.dev).wait_stream(self.branch2)
                         raise
                 pool = g.pool()
+                if reduce_module is not None:
+                    # the gradient tensors THIS graph writes (a later capture rebinds p.grad to its own
+                    # buffers, so the modules' .grad attributes are not a reliable handle on them)
+                    reduce_module = [p.grad for m in reduce_module for p in m.parameters() if p.grad is not None]
                 graphs.append((g, reduce_module))
             self._graphs[update_D] = graphs
             self._keep_alive = getattr(self, "_keep_alive", []) + [dict(self._keep)]
@@ -409,10 +416,10 @@ class GraphedFluidStep:
         self._dev_i.copy_(self._host_i, non_blocking=True)
         for d, t in zip(self._snap, self._state):                       # pre-step snapshot (18 MB, one copy
             d.copy_(t)                                                  # per dtype: the state is flat)
-        for g, reduce_module in self._graphs[update_D]:
+        for g, grads in self._graphs[update_D]:
             g.replay()
-            if reduce_module is not None:
-                self.sync.average_grads(reduce_module)
+            if grads is not None:
+                self.sync.average_tensors(grads)
         # multi-GPU: the decision to leave the graph path must be COLLECTIVE -- the eager step issues
         # other all-reduces than the replay, so every rank falls back as soon as one rank has to
         viol = self.sync.gate_value(self.viol) if self.sync.world_size > 1 else self.viol
