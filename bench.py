@@ -187,11 +187,18 @@ def main():
     # kernel per new shape on a fresh box, which swamps any short run.
     torch.backends.cudnn.enabled = bool(args.miopen)
 
-    rank, world, local = ddp.init_from_env()
+    # TPGAN_DDP_BACKEND=gloo: rehearsal of the multi-rank launch on a box with fewer GPUs than ranks
+    # (ranks share devices, collectives go over gloo); the real run uses nccl = RCCL, one GPU per rank
+    rank, world, local = ddp.init_from_env(backend=os.environ.get("TPGAN_DDP_BACKEND"))
     if world != args.gpus:
         raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run")
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU (the product has no CPU fallback)")
+    if local >= torch.cuda.device_count():
+        if os.environ.get("TPGAN_DDP_BACKEND") != "gloo":
+            raise SystemExit(f"LOCAL_RANK {local} but only {torch.cuda.device_count()} GPU(s) visible")
+        log(f"rank {rank}: REHEARSAL -- sharing cuda:{local % torch.cuda.device_count()} with another rank")
+        local = local % torch.cuda.device_count()
     torch.cuda.set_device(local)
     device = torch.device("cuda", local)
     amp_dtype = torch.bfloat16 if args.dtype == "bf16" else None
