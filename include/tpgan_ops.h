@@ -71,6 +71,14 @@ int tpg_chamfer_bwd_f32(const float *src, const float *tgt, int B, int N, int M,
 int tpg_fps_f32(const float *xyz, int B, int N, int m, float *temp, int32_t *idx,
                 void *stream);
 
+/* Dataset-side farthest point sampling: sampling.py:50-106 `farthest_point_sampling(pts, k,
+ * initial_idx)` (used by train_utils.py:126, train_fluid/tempo_dataset.py:78,
+ * train_action/msr_dataset.py:94,130 on the host, numba): start (B) int32 = first pick per cloud
+ * (NULL = 0), skip_origin = 0 (every point is eligible; 1 = pointnet2's |x|^2 > 1e-3 rule).
+ * Squared distances in fp32, arg-max ties to the smallest index (numpy argmax). */
+int tpg_fps_start_f32(const float *xyz, const int32_t *start, int skip_origin, int B, int N, int m,
+                      float *temp, int32_t *idx, void *stream);
+
 /* gather_operation fwd/bwd -- discriminator.py:131-137.
  * feat (B,C,N), idx (B,S) -> out (B,C,S); bwd overwrites gfeat (B,C,N). */
 int tpg_gather_fwd_f32(const float *feat, const int32_t *idx, int B, int C, int N,

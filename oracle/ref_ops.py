@@ -107,6 +107,17 @@ def fps(xyz, m):
     return idx
 
 
+def fps_start(xyz, m, start=None, skip_origin=False):
+    xyz = _c(xyz, np.float32)
+    B, N, _ = xyz.shape
+    temp = np.empty((B, N), np.float32)
+    idx = np.empty((B, m), np.int32)
+    st = None if start is None else _c(start, np.int32)
+    _chk(lib().tpgref_fps_start_f32(_f(xyz), None if st is None else _i32(st), int(bool(skip_origin)), B, N, m,
+                                    _f(temp), _i32(idx)), "fps_start")
+    return idx
+
+
 def gather_fwd(feat, idx):
     feat, idx = _c(feat, np.float32), _c(idx, np.int32)
     B, Cc, N = feat.shape

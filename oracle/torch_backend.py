@@ -44,8 +44,10 @@ class OracleBackend:
     def chamfer_bwd(self, src, tgt, i1, i2, g1, g2):
         return tuple(_t(x) for x in R.chamfer_bwd(_np(src), _np(tgt), _np(i1), _np(i2), _np(g1), _np(g2)))
 
-    def fps(self, xyz, m):
-        return _t(R.fps(_np(xyz), m))
+    def fps(self, xyz, m, start=None, skip_origin=True):
+        if start is None and skip_origin:
+            return _t(R.fps(_np(xyz), m))
+        return _t(R.fps_start(_np(xyz), m, None if start is None else _np(start), skip_origin))
 
     def gather_fwd(self, feat, idx):
         return _t(R.gather_fwd(_np(feat), _np(idx)))

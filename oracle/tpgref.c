@@ -139,7 +139,16 @@ int tpgref_chamfer_bwd_f32(const float *src, const float *tgt, int B, int N, int
 /* deviation from upstream's block-size dependent tree order).    */
 /* temp is caller-provided scratch (B,N).                                    */
 /* ------------------------------------------------------------------------ */
+int tpgref_fps_start_f32(const float *xyz, const int32_t *start, int skip_origin, int B, int N, int m,
+                         float *temp, int32_t *idx);
 int tpgref_fps_f32(const float *xyz, int B, int N, int m, float *temp, int32_t *idx) {
+    return tpgref_fps_start_f32(xyz, NULL, 1, B, N, m, temp, idx);
+}
+
+/* start (B) = first pick per cloud (NULL: 0); skip_origin = 0: every point eligible -- the  */
+/* dataset-side sampler, sampling.py:50-106 (squared distances, numpy argmax = first maximum) */
+int tpgref_fps_start_f32(const float *xyz, const int32_t *start, int skip_origin, int B, int N, int m,
+                         float *temp, int32_t *idx) {
     if (B < 0 || N <= 0 || m <= 0) return TPG_ERR_ARG;
 #pragma omp parallel for schedule(static)
     for (int b = 0; b < B; ++b) {
@@ -147,8 +156,8 @@ int tpgref_fps_f32(const float *xyz, int B, int N, int m, float *temp, int32_t *
         float *tp = temp + (size_t)b * N;
         int32_t *o = idx + (size_t)b * m;
         for (int k = 0; k < N; ++k) tp[k] = 1e10f;
-        int old = 0;
-        o[0] = 0;
+        int old = start ? (start[b] < 0 ? 0 : (start[b] >= N ? N - 1 : start[b])) : 0;
+        o[0] = old;
         for (int j = 1; j < m; ++j) {
             int besti = 0;
             float best = -1.0f;
@@ -158,7 +167,7 @@ int tpgref_fps_f32(const float *xyz, int B, int N, int m, float *temp, int32_t *
                 float mag = xk[0] * xk[0];
                 mag = mag + xk[1] * xk[1];
                 mag = mag + xk[2] * xk[2];
-                if (mag <= 1e-3f) continue;
+                if (skip_origin && mag <= 1e-3f) continue;
                 const float d = sqdist(xk, xo, 3);
                 const float d2 = d < tp[k] ? d : tp[k];
                 tp[k] = d2;

@@ -22,6 +22,7 @@ SIGNATURES = {
     "tpg_chamfer_fwd_f32": [_P, _P, _I, _I, _I, _P, _P, _P, _P, _P],
     "tpg_chamfer_bwd_f32": [_P, _P, _I, _I, _I, _P, _P, _P, _P, _P, _P, _P],
     "tpg_fps_f32": [_P, _I, _I, _I, _P, _P, _P],
+    "tpg_fps_start_f32": [_P, _P, _I, _I, _I, _I, _P, _P, _P],
     "tpg_gather_fwd_f32": [_P, _P, _I, _I, _I, _I, _P, _P],
     "tpg_gather_bwd_f32": [_P, _P, _I, _I, _I, _I, _P, _P],
     "tpg_ball_query_f32": [_P, _P, _I, _I, _I, _F, _I, _P, _P],

@@ -35,7 +35,8 @@ __device__ __forceinline__ tpg_u64 fps_key(float d2, int k) {
 // which is exactly the reference's `continue`.
 template <int BLOCK, int PPT, bool USE_LDS>
 __global__ __launch_bounds__(BLOCK) void fps_kernel(const float *__restrict__ xyz, int N, int m,
-                                                    int32_t *__restrict__ idx) {
+                                                    int32_t *__restrict__ idx,
+                                                    const int32_t *__restrict__ start, int skip_origin) {
     extern __shared__ __attribute__((aligned(16))) float fps_smem[];
     constexpr int NW = BLOCK / 64;
     // layout: [2][16] (value,index) slots (256 B), then SoA copy of the cloud (USE_LDS)
@@ -61,13 +62,13 @@ __global__ __launch_bounds__(BLOCK) void fps_kernel(const float *__restrict__ xy
         float mag = px[t] * px[t];
         mag = mag + py[t] * py[t];
         mag = mag + pz[t] * pz[t];
-        tp[t] = (in && mag > 1e-3f) ? 1e10f : -1.0f;
+        tp[t] = (in && (!skip_origin || mag > 1e-3f)) ? 1e10f : -1.0f;
         if (USE_LDS && in) { sx[k] = px[t]; sy[k] = py[t]; sz[k] = pz[t]; }
     }
-    if (tid == 0) out[0] = 0;
+    int old = start ? tpg_clamp_idx(start[blockIdx.x], N) : 0;       // pointnet2: always point 0
+    if (tid == 0) out[0] = old;
     if (NW > 1 || USE_LDS) __syncthreads();
 
-    int old = 0;
     for (int j = 1; j < m; ++j) {
         float ox, oy, oz;
         if (USE_LDS) { ox = sx[old]; oy = sy[old]; oz = sz[old]; }
@@ -105,16 +106,17 @@ __global__ __launch_bounds__(BLOCK) void fps_kernel(const float *__restrict__ xy
 // fallback for clouds too large for registers: running distances in HBM scratch.
 __global__ __launch_bounds__(1024) void fps_big_kernel(const float *__restrict__ xyz, int N, int m,
                                                        float *__restrict__ temp,
-                                                       int32_t *__restrict__ idx) {
+                                                       int32_t *__restrict__ idx,
+                                                       const int32_t *__restrict__ start, int skip_origin) {
     __shared__ tpg_u64 slots[2][16];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const float *x = xyz + (size_t)blockIdx.x * N * 3;
     float *tp = temp + (size_t)blockIdx.x * N;
     int32_t *out = idx + (size_t)blockIdx.x * m;
     for (int k = tid; k < N; k += 1024) tp[k] = 1e10f;
-    if (tid == 0) out[0] = 0;
+    int old = start ? tpg_clamp_idx(start[blockIdx.x], N) : 0;
+    if (tid == 0) out[0] = old;
     __syncthreads();
-    int old = 0;
     for (int j = 1; j < m; ++j) {
         const float ox = x[(size_t)old * 3], oy = x[(size_t)old * 3 + 1], oz = x[(size_t)old * 3 + 2];
         float best = -1.0f;
@@ -124,7 +126,7 @@ __global__ __launch_bounds__(1024) void fps_big_kernel(const float *__restrict__
             float mag = ax * ax;
             mag = mag + ay * ay;
             mag = mag + az * az;
-            if (mag <= 1e-3f) continue;
+            if (skip_origin && mag <= 1e-3f) continue;
             const float d = tpg_sq3(ax, ay, az, ox, oy, oz);
             const float t0 = tp[k];
             const float d2 = d < t0 ? d : t0;
@@ -148,7 +150,8 @@ __global__ __launch_bounds__(1024) void fps_big_kernel(const float *__restrict__
 }
 
 template <int BLOCK, int PPT>
-void fps_go(const float *xyz, int B, int N, int m, int32_t *idx, hipStream_t st) {
+void fps_go(const float *xyz, int B, int N, int m, int32_t *idx, const int32_t *start, int skip_origin,
+            hipStream_t st) {
     int use_lds = N <= FPS_LDS_POINTS;
     size_t smem = 256 + (use_lds ? sizeof(float) * 3 * (size_t)N : 0);
     if (smem > 48 * 1024) {
@@ -168,30 +171,37 @@ void fps_go(const float *xyz, int B, int N, int m, int32_t *idx, hipStream_t st)
         }
     }
     if (use_lds)
-        hipLaunchKernelGGL((fps_kernel<BLOCK, PPT, true>), dim3(B), dim3(BLOCK), smem, st, xyz, N, m, idx);
+        hipLaunchKernelGGL((fps_kernel<BLOCK, PPT, true>), dim3(B), dim3(BLOCK), smem, st, xyz, N, m, idx, start,
+                           skip_origin);
     else
-        hipLaunchKernelGGL((fps_kernel<BLOCK, PPT, false>), dim3(B), dim3(BLOCK), smem, st, xyz, N, m, idx);
+        hipLaunchKernelGGL((fps_kernel<BLOCK, PPT, false>), dim3(B), dim3(BLOCK), smem, st, xyz, N, m, idx, start,
+                           skip_origin);
 }
 
 }  // namespace
 
-extern "C" int tpg_fps_f32(const float *xyz, int B, int N, int m, float *temp, int32_t *idx,
-                           void *stream) {
+extern "C" int tpg_fps_start_f32(const float *xyz, const int32_t *start, int skip_origin, int B, int N, int m,
+                                 float *temp, int32_t *idx, void *stream) {
     if (B < 0 || N <= 0 || m <= 0) return TPG_ERR_ARG;
     if (B == 0) return TPG_OK;
     if (!xyz || !idx) return TPG_ERR_ARG;
     hipStream_t st = tpg_stream(stream);
-    if (N <= 256) fps_go<64, 4>(xyz, B, N, m, idx, st);
-    else if (N <= 512) fps_go<128, 4>(xyz, B, N, m, idx, st);
-    else if (N <= 1024) fps_go<256, 4>(xyz, B, N, m, idx, st);
-    else if (N <= 2048) fps_go<512, 4>(xyz, B, N, m, idx, st);
-    else if (N <= 4096) fps_go<1024, 4>(xyz, B, N, m, idx, st);
-    else if (N <= 8192) fps_go<1024, 8>(xyz, B, N, m, idx, st);
-    else if (N <= 16384) fps_go<1024, 16>(xyz, B, N, m, idx, st);
+    if (N <= 256) fps_go<64, 4>(xyz, B, N, m, idx, start, skip_origin, st);
+    else if (N <= 512) fps_go<128, 4>(xyz, B, N, m, idx, start, skip_origin, st);
+    else if (N <= 1024) fps_go<256, 4>(xyz, B, N, m, idx, start, skip_origin, st);
+    else if (N <= 2048) fps_go<512, 4>(xyz, B, N, m, idx, start, skip_origin, st);
+    else if (N <= 4096) fps_go<1024, 4>(xyz, B, N, m, idx, start, skip_origin, st);
+    else if (N <= 8192) fps_go<1024, 8>(xyz, B, N, m, idx, start, skip_origin, st);
+    else if (N <= 16384) fps_go<1024, 16>(xyz, B, N, m, idx, start, skip_origin, st);
     else {
         if (!temp) return TPG_ERR_ARG;
-        hipLaunchKernelGGL(fps_big_kernel, dim3(B), dim3(1024), 0, st, xyz, N, m, temp, idx);
+        hipLaunchKernelGGL(fps_big_kernel, dim3(B), dim3(1024), 0, st, xyz, N, m, temp, idx, start, skip_origin);
     }
     TPG_RETURN_IF_LAUNCH_FAILED();
     return TPG_OK;
+}
+
+extern "C" int tpg_fps_f32(const float *xyz, int B, int N, int m, float *temp, int32_t *idx,
+                           void *stream) {
+    return tpg_fps_start_f32(xyz, nullptr, 1, B, N, m, temp, idx, stream);     // pointnet2 semantics
 }

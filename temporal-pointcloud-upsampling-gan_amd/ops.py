@@ -166,11 +166,15 @@ class HipBackend:
                    _ptr(src), _ptr(tgt), B, N, M, _ptr(i1), _ptr(i2), _ptr(g1), _ptr(g2), _ptr(gs), _ptr(gt))
         return gs, gt
 
-    def fps(self, xyz, m):
+    def fps(self, xyz, m, start=None, skip_origin=True):
         B, N, _ = xyz.shape
         idx = torch.empty((B, m), dtype=torch.int32, device=xyz.device)
         temp = torch.empty((B, N), dtype=torch.float32, device=xyz.device) if N > 16384 else None
-        self._call("tpg_fps_f32", "fps", 12 * B * N + 4 * B * m, xyz, _ptr(xyz), B, N, m, _ptr(temp), _ptr(idx))
+        if start is None and skip_origin:
+            self._call("tpg_fps_f32", "fps", 12 * B * N + 4 * B * m, xyz, _ptr(xyz), B, N, m, _ptr(temp), _ptr(idx))
+        else:
+            self._call("tpg_fps_start_f32", "fps", 12 * B * N + 4 * B * m, xyz, _ptr(xyz), _ptr(start),
+                       int(bool(skip_origin)), B, N, m, _ptr(temp), _ptr(idx))
         return idx
 
     def gather_fwd(self, feat, idx):
@@ -443,6 +447,39 @@ def furthest_point_sample(xyz, npoint):
     _need(int(npoint) > 0 and xyz.shape[1] > 0, "npoint and N must be positive")
     with torch.no_grad():
         return backend_for(xyz).fps(xyz.detach(), int(npoint))
+
+
+def farthest_point_sampling(pts, k, initial_idx=None):
+    """Dataset-side FPS (sampling.py:50-106, used by train_utils.py:126, tempo_dataset.py:78,
+    msr_dataset.py:94,130 through numba on the host): every point eligible, first pick
+    `initial_idx` (None = random, np.random like the reference).  pts (N,3) or (B,N,3) on the
+    GPU -> indices (k,) / (B,k) int64."""
+    single = pts.dim() == 2
+    x = (pts.unsqueeze(0) if single else pts).detach().float().contiguous()
+    _need(x.dim() == 3 and x.shape[2] == 3, "pts must be (N,3) or (B,N,3)")
+    B, N, _ = x.shape
+    if initial_idx is None:
+        initial_idx = [int(np.random.randint(N)) for _ in range(B)]
+    start = torch.as_tensor(initial_idx, dtype=torch.int32).reshape(-1).expand(B).contiguous().to(x.device)
+    idx = backend_for(x).fps(x, int(k), start, False).long()
+    return idx[0] if single else idx
+
+
+def sample_patch_with_fps(input_pos, patch_num, ds_ratio=0.125, seed_idx=None, initial_idx=None):
+    """train_utils.py:98-139 on the GPU: the `patch_num` nearest neighbours of a random seed
+    point (the reference queries a KD-tree) and their FPS down-sampling to `ds_ratio` of the patch.
+    input_pos (N,3) -> dict(patch_pos, ds_pos, patch_idx, fps_idx).  The K = thousands
+    selection is one `torch.topk` over the N distances to the seed (a single query: nothing to
+    tile), FPS is the HIP kernel."""
+    x = input_pos.detach().float()
+    N = x.shape[0]
+    if seed_idx is None:
+        seed_idx = int(np.random.choice(N))
+    d = ((x - x[seed_idx]) ** 2).sum(-1)
+    patch = torch.topk(d, min(int(patch_num), N), largest=False, sorted=True).indices
+    patch_pos = x[patch].contiguous()
+    fps_idx = farthest_point_sampling(patch_pos, int(ds_ratio * patch_pos.shape[0]), initial_idx)
+    return {"patch_pos": patch_pos, "ds_pos": patch_pos[fps_idx], "patch_idx": patch, "fps_idx": fps_idx}
 
 
 class _Gather(torch.autograd.Function):

@@ -483,3 +483,17 @@ def test_cubic_interpolation_selects_padding_per_cloud(hip):
     assert np.array_equal(out[0], plain[0])
     assert np.array_equal(out[1], np.where((hits[1] < 32)[:, None], pad[1], plain[1]))
     assert (hits[1] < 32).any() and not np.array_equal(pad[1], plain[1])
+
+
+@pytest.mark.parametrize("N,m", [(4096, 512), (9216, 1152), (300, 40), (20000, 64)])
+def test_dataset_fps_matches_oracle(hip, N, m):
+    """tpg_fps_start_f32: random first pick, every point eligible (sampling.py:50-106)."""
+    rng = np.random.default_rng(N)
+    pts = (rng.standard_normal((3, N, 3)) * 0.3).astype(np.float32)
+    pts[0, 7] = 0.0
+    start = rng.integers(0, N, 3).astype(np.int32)
+    got = hip.fps(dev(pts), m, dev(start), False).cpu().numpy()
+    assert np.array_equal(got, R.fps_start(pts, m, start, skip_origin=False))
+    assert np.array_equal(got[:, 0], start)
+    # the pointnet2 rule is unchanged
+    assert np.array_equal(hip.fps(dev(pts), m).cpu().numpy(), R.fps(pts, m))

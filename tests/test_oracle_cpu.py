@@ -213,3 +213,31 @@ def test_cubic_interpolation_matches_the_reference_algorithm(case, oracle_cpu):
     # the per-sample 2-D signature of the reference
     one = ops.cubic_interpolation(torch.from_numpy(query[1]), torch.from_numpy(field[1]), torch.from_numpy(pos[1]), cutoff)
     assert np.array_equal(one.numpy(), got[1])
+
+
+def test_dataset_fps_random_start_no_origin_skip(oracle_cpu):
+    """sampling.py:50-106 restated in numpy (squared fp32 distances, argmax = first maximum, start
+    index given, NO |x|^2 > 1e-3 rule) against the oracle's start variant and ops.farthest_point_sampling."""
+    import torch
+    import tpgan_amd.ops as ops
+    rng = np.random.default_rng(4)
+    pts = rng.standard_normal((2, 700, 3)).astype(np.float32) * 0.2
+    pts[0, 5] = 0.0                                    # at the origin: eligible here, skipped by pointnet2's rule
+    pts[1, :40] *= 0.05
+    start = np.array([17, 300], np.int32)
+    got = R.fps_start(pts, 64, start, skip_origin=False)
+    for b in range(2):
+        x = pts[b]
+        idx = [int(start[b])]
+        mind = ((x - x[idx[0]]) ** 2).sum(-1, dtype=np.float32)
+        for _ in range(63):
+            j = int(np.argmax(mind))
+            idx.append(j)
+            mind = np.minimum(mind, ((x - x[j]) ** 2).sum(-1, dtype=np.float32))
+        assert np.array_equal(got[b], np.array(idx)), b
+    t = ops.farthest_point_sampling(torch.from_numpy(pts), 64, initial_idx=start.tolist())
+    assert np.array_equal(t.numpy(), got)
+    one = ops.farthest_point_sampling(torch.from_numpy(pts[1]), 64, initial_idx=300)
+    assert np.array_equal(one.numpy(), got[1])
+    d = ops.sample_patch_with_fps(torch.from_numpy(pts[0]), 256, seed_idx=3, initial_idx=0)
+    assert d["patch_pos"].shape == (256, 3) and d["ds_pos"].shape == (32, 3) and int(d["patch_idx"][0]) == 3
