@@ -110,8 +110,26 @@ class GraphedFluidStep:
         self.dev, self.T, self.B = dev, len(highres_pos_lst), lowres_pos_lst[0].shape[0]
         self.low = [torch.empty_like(x) for x in lowres_pos_lst]
         self.high = [torch.empty_like(x) for x in highres_pos_lst]
-        n_pred = lowres_pos_lst[0].shape[1] * sr_net.upsample_ratio
-        T, B = self.T, self.B
+        self._setup_staging(lowres_pos_lst[0].shape[1] * sr_net.upsample_ratio)
+        self.report = torch.zeros(6, device=dev)
+        self.viol = torch.zeros(1, device=dev)
+        # index-plan streams: [0] the temporal discriminator's clouds, [1] the spatial one's (real
+        # clouds at the start of the step, fake ones as soon as the generator's forward is done)
+        self.sides = [torch.cuda.Stream(dev) for _ in range(2)]
+        self.branch = torch.cuda.Stream(dev)       # the discriminators' updates
+        self.branch2 = torch.cuda.Stream(dev)
+        self.use_plans = True
+        self._keep = {}
+        self._graphs = None
+        self._capture(lowres_pos_lst, highres_pos_lst, warmup)
+
+    KEYS = ["tempo_G_loss", "tempo_D_loss", "Chamfer_distance_no_norm", "masking_loss", "spatial_G_loss",
+            "spatial_D_loss"]
+    EAGER_UNTIL = 10          # n_iter <= 10: the mask loss is a placeholder (another regime): eager
+
+    def _setup_staging(self, n_pred):
+        """Static device tensors the host-drawn randomness of a step travels through."""
+        dev, T, B = self.dev, self.T, self.B
         # host-drawn inputs of a step travel through ONE persistent pinned staging buffer per dtype
         # (an async copy from a temporary pageable tensor may read freed memory on HIP)
         nf = 4 + 9 * (2 * T + 2 * B)
@@ -132,18 +150,6 @@ class GraphedFluidStep:
         self._host_f[4:] = eye.repeat(2 * T + 2 * B)
         self._host_f[:4] = torch.tensor([1.0, 0.1, 1.0, 1.0])
         self._dev_f.copy_(self._host_f)
-        self.report = torch.zeros(6, device=dev)
-        self.viol = torch.zeros(1, device=dev)
-        # index-plan streams: [0] temporal-D clouds, [1] spatial-D clouds (real at the start of the
-        # step, fake as soon as the generator's forward is done: FIFO order = data dependency of
-        # merge_plans), [2] / [3] the generator step's own spatial / temporal forward
-        self.sides = [torch.cuda.Stream(dev) for _ in range(2)]
-        self.branch = torch.cuda.Stream(dev)       # the discriminators' updates (single-GPU form)
-        self.branch2 = torch.cuda.Stream(dev)
-        self.use_plans = True
-        self._keep = {}
-        self._graphs = None
-        self._capture(lowres_pos_lst, highres_pos_lst, warmup)
 
     # ------------------------------------------------------------------ step body (capturable)
     def _plan(self, make, which):
@@ -383,14 +389,9 @@ class GraphedFluidStep:
         torch.cuda.synchronize(self.dev)
 
     # ------------------------------------------------------------------ one training step
-    def __call__(self, lowres_pos_lst, highres_pos_lst, n_iter, freeze_D=False):
-        """Same contract as gan_step.tempo_gan_step (without velocities); returns its loss dict."""
-        update_D = n_iter % 2 == 0 and not freeze_D
-        if n_iter <= 10:
-            return self._eager(lowres_pos_lst, highres_pos_lst, n_iter, freeze_D)
-        np_state, cpu_rng = np.random.get_state(), torch.get_rng_state()
-        cuda_rng = torch.cuda.get_rng_state(self.dev)
-        # host draws, in the reference's order (train_step_final.py:85-90,121,152,171-204)
+    def _stage_host_draws(self, update_D):
+        """Draw the step's host randomness in the reference's order (train_step_final.py:85-90,121,
+        152,171-204) into the pinned staging buffers."""
         valid, invalid = np.random.uniform(0.8, 1.2), np.random.uniform(0.0, 0.2)
         if np.random.uniform(0.0, 1.0) < 0.03:
             valid, invalid = invalid, valid
@@ -407,11 +408,20 @@ class GraphedFluidStep:
             if np.random.uniform() > 0.7:
                 rts = [get_rotation_matrix() for _ in range(self.B)]
                 rfs = [get_rotation_matrix() for _ in range(self.B)]
-        self._load(lowres_pos_lst, highres_pos_lst)
         # (the previous step ended with a host sync, so the staging buffers are free to rewrite)
         self._host_f[:4] = torch.tensor([valid, invalid, lab_s, lab_t], dtype=torch.float32)
         self._host_f[4:] = torch.stack(rft + rtt + rfs + rts).reshape(-1)
         self._host_i.copy_(torch.cat(perms))
+
+    def __call__(self, lowres_pos_lst, highres_pos_lst, n_iter, freeze_D=False):
+        """Same contract as the eager step function (without velocities); returns its loss dict."""
+        update_D = n_iter % 2 == 0 and not freeze_D
+        if n_iter <= self.EAGER_UNTIL:
+            return self._eager(lowres_pos_lst, highres_pos_lst, n_iter, freeze_D)
+        np_state, cpu_rng = np.random.get_state(), torch.get_rng_state()
+        cuda_rng = torch.cuda.get_rng_state(self.dev)
+        self._stage_host_draws(update_D)
+        self._load(lowres_pos_lst, highres_pos_lst)
         self._dev_f.copy_(self._host_f, non_blocking=True)
         self._dev_i.copy_(self._host_i, non_blocking=True)
         for d, t in zip(self._snap, self._state):                       # pre-step snapshot (18 MB, one copy
@@ -432,9 +442,7 @@ class GraphedFluidStep:
             torch.set_rng_state(cpu_rng)
             torch.cuda.set_rng_state(cuda_rng, self.dev)
             return self._eager(lowres_pos_lst, highres_pos_lst, n_iter, freeze_D)
-        keys = ["tempo_G_loss", "tempo_D_loss", "Chamfer_distance_no_norm", "masking_loss", "spatial_G_loss",
-                "spatial_D_loss"]
-        return dict(zip(keys, out[:6]))
+        return {k: v for k, v in zip(self.KEYS, out[:6]) if k is not None}
 
     def run_body_eagerly(self, lowres_pos_lst, highres_pos_lst, update_D=True):
         """One step through the SAME body the graphs were captured from, launched kernel by kernel
@@ -442,10 +450,104 @@ class GraphedFluidStep:
         self._load(lowres_pos_lst, highres_pos_lst)
         self._run_eager(update_D)
         torch.cuda.synchronize(self.dev)
-        keys = ["tempo_G_loss", "tempo_D_loss", "Chamfer_distance_no_norm", "masking_loss", "spatial_G_loss",
-                "spatial_D_loss"]
-        return dict(zip(keys, self.report.cpu().tolist()))
+        return {k: v for k, v in zip(self.KEYS, self.report.cpu().tolist()) if k is not None}
 
     def _eager(self, low, high, n_iter, freeze_D):
         return tempo_gan_step(self.G, self.Ds, self.Dt, low, None, high, None, self.fd, self.opt, n_iter, self.og,
                               self.ot, self.os, freeze_D, sync=self.sync, amp_dtype=self.amp)
+
+
+class GraphedActionStep(GraphedFluidStep):
+    """`gan_step.tempo_gan_step_no_mask` (train_step_final.py:233-320) replayed from hipGraphs: the
+    action-clip step has no mask head, no gate and no rotation augmentation, so it is ALWAYS in its
+    static regime (the violation flag stays 0).  Same structure as the fluid step: stacked
+    generator call, index plans on their own streams, fake / real batch of each discriminator
+    update as segments of one pass, the three backward chains as parallel branches.
+
+    optims = (generator, temporal-D, spatial-D) optimizers, capturable."""
+
+    KEYS = ["tempo_G_loss", "tempo_D_loss", "Chamfer_distance_no_norm", None, "spatial_G_loss", "spatial_D_loss"]
+    EAGER_UNTIL = -1
+
+    def _setup_staging(self, n_pred):
+        dev, T = self.dev, self.T
+        self._host_f = torch.zeros(4, dtype=torch.float32).pin_memory()
+        self._host_i = torch.zeros((T + 2) * n_pred, dtype=torch.int64).pin_memory()
+        self._dev_f = torch.tensor([1.0, 0.1, 1.0, 1.0], device=dev)
+        self._host_f.copy_(self._dev_f.cpu())
+        self._dev_i = torch.arange(n_pred, device=dev).repeat(T + 2).contiguous()
+        self.lab = self._dev_f
+        v = self._dev_i.view(T + 2, n_pred)
+        # randperm draws of the reference, in its order: spatial G forward, centre frame, the other
+        # frames, spatial D update (train_step_final.py:249,262,270,304)
+        self.perm_sg, self.perm_c, self.perm_f, self.perm_sd = v[0], v[1], [v[2 + i] for i in range(T - 1)], v[T + 1]
+
+    def _stage_host_draws(self, update_D):
+        valid, invalid = np.random.uniform(0.8, 1.2), np.random.uniform(0.0, 0.2)
+        if np.random.uniform(0.0, 1.0) < 0.03:
+            valid, invalid = invalid, valid
+        n_pred = self.perm_c.numel()
+        perm_sg = torch.randperm(n_pred)
+        lab_s = np.random.uniform(0.8, 1.2)
+        perms = [torch.randperm(n_pred) for _ in range(self.T)]
+        lab_t = np.random.uniform(0.8, 1.2)
+        perm_sd = torch.randperm(n_pred) if update_D else torch.arange(n_pred)
+        self._host_f.copy_(torch.tensor([valid, invalid, lab_s, lab_t], dtype=torch.float32))
+        self._host_i.copy_(torch.cat([perm_sg] + perms + [perm_sd]))
+
+    def _seg_generator(self, update_D, defer_backward=False):
+        G, Ds, Dt, opt, k = self.G, self.Ds, self.Dt, self.opt, self._keep
+        low, high, lab = self.low, self.high, self.lab
+        others = [0] + list(range(2, self.T))
+        order = [1] + others
+        if update_D:                       # the real clouds exist already: their index plans start now
+            (k["trues"], k["plan_true_t"]), _ = run_index_plan(
+                lambda: (list(high), Dt.index_plan(list(high), opt.R) if self.use_plans else None), self.sides[0])
+            (k["true_s"], k["plan_true_s"]), _ = run_index_plan(
+                lambda: (high[1], Ds.index_plan(high[1]) if self.use_plans else None), self.sides[1])
+        with _frozen(Ds, Dt), _autocast(self.amp, self.dev):
+            edge_all = G.body(torch.cat([low[f] for f in order], 0))
+            edges = edge_all.reshape(len(order), self.B, *edge_all.shape[1:]).unbind(0)
+            pred_c = G.expand_pos(low[1], edges[0]).float()
+            fake_s_in = pred_c.index_select(1, self.perm_sg)
+            plan_fs, join_fs = self._plan(lambda: Ds.index_plan(fake_s_in), 1)
+            position_loss, cd, _ = tpugan_sr_loss(0, high[1], pred_c, 0., 0., 0., 0)
+            pred_lst = [None] * self.T
+            pred_lst[1] = pred_c.index_select(1, self.perm_c)
+            for i, f in enumerate(others):
+                pred_lst[f] = G.expand_pos(low[f], edges[i + 1]).float().index_select(1, self.perm_f[i])
+            plan_ft, join_ft = self._plan(lambda: Dt.merge_plans([Dt.index_plan(pred_lst, opt.R)]), 0)
+            if update_D:
+                def fake_t():
+                    fakes = [p.detach() for p in pred_lst]
+                    if not self.use_plans:
+                        return fakes, None
+                    return fakes, Dt.merge_plans([Dt.index_plan(fakes, opt.R), k["plan_true_t"]])
+
+                def fake_s_():
+                    fake_s = pred_c.detach().index_select(1, self.perm_sd)
+                    if not self.use_plans:
+                        return fake_s, None
+                    return fake_s, Ds.merge_plans([Ds.index_plan(fake_s), k["plan_true_s"]])
+                (k["fakes"], k["plan_t"]), _ = run_index_plan(fake_t, self.sides[0])
+                (k["fake_s"], k["plan_s"]), _ = run_index_plan(fake_s_, self.sides[1])
+            join_fs()
+            fake = Ds(fake_s_in, plan=plan_fs)
+            spatial_loss = (0.5 * (fake.float() - lab[2]) ** 2).mean()
+            join_ft()
+            fake = Dt.forward_passes([pred_lst], opt.R, plan=plan_ft)[0]
+            tempo_loss = (0.5 * (fake.float() - lab[3]) ** 2).mean()
+        sr_loss = tempo_loss + spatial_loss + opt.w * position_loss
+        k.update(tempo_loss=tempo_loss.detach(), spatial_loss=spatial_loss.detach(), cd=cd.detach(),
+                 ml=torch.zeros((), device=self.dev))
+        self.viol.zero_()
+        if defer_backward:
+            return sr_loss
+        self.og.zero_grad(set_to_none=True)
+        sr_loss.backward()
+        self._join_sides()
+
+    def _eager(self, low, high, n_iter, freeze_D):
+        from .gan_step import tempo_gan_step_no_mask
+        return tempo_gan_step_no_mask(self.G, self.Ds, self.Dt, low, high, self.opt, n_iter, self.og, self.ot,
+                                      self.os, freeze_D, sync=self.sync, amp_dtype=self.amp)

@@ -106,3 +106,47 @@ def test_violation_falls_back_to_eager_with_identical_result():
     for ma, mb in zip(A, Bm):
         for pa, pb in zip(ma.state_dict().values(), mb.state_dict().values()):
             assert torch.equal(pa, pb)
+
+
+def test_action_graph_replay_equals_eager():
+    """GraphedActionStep against tempo_gan_step_no_mask: one step from identical state with identical
+    host draws (labels, five permutations); then it keeps replaying (odd and even iterations)."""
+    from tpgan_amd.gan_step import tempo_gan_step_no_mask
+    from tpgan_amd.gan_step_graph import GraphedActionStep
+    from tpgan_amd.set_abstraction import ActionSpatialDis, ActionTempoDis
+    from tpgan_amd.srnet import NoMaskSRNet
+    from tpgan_amd.synthetic import action_clip
+    dev = torch.device("cuda", 0)
+    torch.manual_seed(5)
+    A = (NoMaskSRNet(3, 128, upsample_ratio=16).to(dev), ActionSpatialDis().to(dev), ActionTempoDis(3).to(dev))
+    for m in list(A[1].modules()) + list(A[2].modules()):
+        if isinstance(m, torch.nn.Dropout):
+            m.p = 0.0
+    Bm = copy.deepcopy(A)
+    oa, ob = _optims(*A), _optims(*Bm)
+    opt = Namespace(R=2.0, w=2.0)
+    clips = [action_clip(4, 2048, 16, 3, seed=s, device=dev) for s in (1, 2)]
+    init = [[p.detach().clone() for p in m.parameters()] for m in A]
+    stepper = GraphedActionStep(Bm[0], Bm[1], Bm[2], ob, opt, clips[0][0], clips[0][1], 1.0, None, None)
+    for pa, pb in zip(A[0].parameters(), Bm[0].parameters()):
+        assert torch.equal(pa, pb)
+    low, high = clips[0]
+    np.random.seed(21); torch.manual_seed(21)
+    le = tempo_gan_step_no_mask(A[0], A[1], A[2], low, high, opt, 12, oa[0], oa[1], oa[2])
+    np.random.seed(21); torch.manual_seed(21)
+    lg = stepper(low, high, 12)
+    assert set(le) == set(lg)
+    for k in le:
+        assert abs(le[k] - lg[k]) <= 2e-3 * max(1.0, abs(le[k])), (k, le[k], lg[k])
+    assert le["tempo_D_loss"] > 0
+    for ma, mb, m0 in zip(A, Bm, init):
+        da = torch.cat([(p - q).reshape(-1) for p, q in zip(ma.parameters(), m0)])
+        db = torch.cat([(p - q).reshape(-1) for p, q in zip(mb.parameters(), m0)])
+        assert float(da.norm()) > 0
+        rel = float((da - db).norm() / da.norm())
+        print("action: relative L2 difference of the parameter deltas:", rel)
+        assert rel <= 3e-2, rel
+    for it, (low, high) in zip((13, 14), (clips[1], clips[0])):
+        lg = stepper(low, high, it)
+        assert all(np.isfinite(v) for v in lg.values())
+        assert (lg["tempo_D_loss"] > 0) == (it % 2 == 0)
