@@ -12,7 +12,7 @@ import torch
 
 spec = importlib.util.spec_from_file_location("bench", os.path.join(ROOT, "bench.py"))
 b = importlib.util.module_from_spec(spec)
-sys.argv = ["bench.py"]
+argv_saved, sys.argv = sys.argv, ["bench.py"]
 spec.loader.exec_module(b)
 torch.backends.cudnn.enabled = False
 dev = torch.device("cuda", 0)
@@ -22,7 +22,9 @@ clips = [b.fluid_clip(8, 4096, 8, 3, seed=s, device=dev) for s in range(4)]
 from tpgan_amd.gan_step_graph import GraphedFluidStep
 G, Ds, Dt, opts = models
 step = GraphedFluidStep(G, Ds, Dt, opts, b.OPT, clips[0][0], clips[0][1], 1.0, torch.bfloat16, None)
-for n_iter, label in ((12, "G + both D updates"), (13, "G only")):
+which = argv_saved[1] if len(argv_saved) > 1 else "both"      # "odd": only the generator-only graph (for rocprofv3 --stats)
+cases = ((13, "G only"),) if which == "odd" else ((12, "G + both D updates"), (13, "G only"))
+for n_iter, label in cases:
     for i in range(3):
         step(*clips[i % 4], n_iter)
     torch.cuda.synchronize()
