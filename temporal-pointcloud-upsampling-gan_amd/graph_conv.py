@@ -326,12 +326,19 @@ class EdgeConv(nn.Module):
         self._rows_ok = self.norm == "none" and not sn
 
     # ---- channels-last fast path ---------------------------------------------------------
-    def forward_rows(self, x, pos=None):
-        """x (B,N,C) rows [, pos (B,N,3) to search in] -> (B,N,C_out)."""
+    def forward_rows(self, x, pos=None, knn_idx=None):
+        """x (B,N,C) rows [, pos (B,N,3) to search in] -> (B,N,C_out).
+        knn_idx: an already searched neighbour list of the same points with at least this
+        layer's k entries (the first k of a longer kNN list ARE the k-NN list: canonical
+        ascending (dist, idx) order); the layer's own dilation is applied to it."""
         if not (self._rows_ok and rows_first()):
             return self._forward_planes(x.transpose(1, 2), pos).squeeze(-1).transpose(1, 2)
         x = x.contiguous()
-        idx = self.dilated_knn_graph(pos if pos is not None else x).to(torch.int32).contiguous()
+        if knn_idx is not None:
+            g = self.dilated_knn_graph
+            idx = g._dilated(knn_idx[:, :, :g.k]).to(torch.int32).contiguous()
+        else:
+            idx = self.dilated_knn_graph(pos if pos is not None else x).to(torch.int32).contiguous()
         with no_autocast(x):
             xf = x.float()
             A = F.leaky_relu(rows_linear(self.node_affine[0], xf), 0.2)  # (B,N,H)
@@ -395,15 +402,20 @@ class IDGCNLayer(nn.Module):
             return self._forward_planes(x.transpose(1, 2).unsqueeze(-1)).squeeze(-1).transpose(1, 2)
         skip = rows_seq(self.skip_layer, x) if self.residual else None
         low = rows_seq(self.btn, x).contiguous()                        # (B,N,C/4)
-        _, idx = ops.neighbour_search(low, low, 9)
-        local = ops.row_combine(low, None, idx.to(torch.int32), ops.ROW_GATHER)   # (B,N,9,C/4)
+        # ONE search serves the three neighbour lists built on `low` (gcn.py:253-262 searches three
+        # times): the local 9-NN list and the two EdgeConvs' k-NN lists are prefixes of the longest
+        kmax = max(9, self.GCN1.dilated_knn_graph.k, self.GCN2.dilated_knn_graph.k)
+        _, idx_all = ops.neighbour_search(low, low, kmax)
+        idx = idx_all[:, :, :9]
+        local = ops.row_combine(low, None, idx.to(torch.int32).contiguous(), ops.ROW_GATHER)   # (B,N,9,C/4)
         B, N, k, q = local.shape
         if q % 8 == 0 and low.dtype in (torch.float32, torch.bfloat16):
             # max over the 9 neighbours with a one-byte arg-max and a one-pass backward
             local_max = ops.row_act_max(local.view(B * N * k, q), 1.0, k).view(B, N, q)
         else:
             local_max = local.max(2)[0]
-        out = torch.cat([local_max, self.GCN1.forward_rows(low), self.GCN2.forward_rows(low)], dim=-1)
+        out = torch.cat([local_max, self.GCN1.forward_rows(low, knn_idx=idx_all),
+                         self.GCN2.forward_rows(low, knn_idx=idx_all)], dim=-1)
         out = rows_seq(self.decoder, out)
         if self.use_layernorm:
             out = self.layernorm(out)
