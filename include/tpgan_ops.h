@@ -208,8 +208,11 @@ int tpg_spectral_norm_bwd(const float *G, const float *Wsn, const float *u, cons
 long long tpg_spectral_norm_multi_stride(int R, int Cn);
 int tpg_spectral_norm_multi_fwd(const void *desc, int M, int max_rc, float *out, int iterate, float eps,
                                 void *stream);
-int tpg_spectral_norm_multi_bwd(const void *desc, int M, const float *g, const float *out, float *dw,
-                                void *stream);
+/* backward: max_uses = max over m of uses (<= 64); scratch: tpg_spectral_norm_multi_bwd_scratch(M, max_uses)
+ * floats (the partial inner products <G_t, Wsn_t> of the row chunks, summed in fixed order). */
+long long tpg_spectral_norm_multi_bwd_scratch(int M, int max_uses);
+int tpg_spectral_norm_multi_bwd(const void *desc, int M, int max_uses, const float *g, const float *out,
+                                float *dw, float *scratch, void *stream);
 
 /* ---- fused radius search + bicubic weighted average (the `--use_vel` advection features) ----
  * gcn_lib/interpolation.py:107-123 `cubic_interpolation(query_pos, field, pos, cutoff)` over

@@ -40,10 +40,10 @@ SIGNATURES = {
     "tpg_spectral_norm_fwd": [_P, _P, _P, _I, _I, _I, _F, _P, _P, _P],
     "tpg_spectral_norm_bwd": [_P, _P, _P, _P, _P, _I, _I, _P, _P],
     "tpg_spectral_norm_multi_fwd": [_P, _I, _I, _P, _I, _F, _P],
-    "tpg_spectral_norm_multi_bwd": [_P, _I, _P, _P, _P, _P],
+    "tpg_spectral_norm_multi_bwd": [_P, _I, _I, _P, _P, _P, _P, _P],
 }
 SIZE_GETTERS = ("tpg_rowbn_workspace_bytes",)
-OTHER_GETTERS = ("tpg_spectral_norm_multi_stride",)
+OTHER_GETTERS = ("tpg_spectral_norm_multi_stride", "tpg_spectral_norm_multi_bwd_scratch")
 STRING_GETTERS = ("tpg_version", "tpg_target_arch")
 
 STATUS = {0: "TPG_OK", -1: "TPG_ERR_ARG", -2: "TPG_ERR_LAUNCH", -3: "TPG_ERR_UNSUPPORTED"}
@@ -76,6 +76,8 @@ def load():
         getattr(lib, name).restype = C.c_size_t
     lib.tpg_spectral_norm_multi_stride.argtypes = [C.c_int, C.c_int]
     lib.tpg_spectral_norm_multi_stride.restype = C.c_longlong
+    lib.tpg_spectral_norm_multi_bwd_scratch.argtypes = [C.c_int, C.c_int]
+    lib.tpg_spectral_norm_multi_bwd_scratch.restype = C.c_longlong
     _lib = lib
     return lib
 

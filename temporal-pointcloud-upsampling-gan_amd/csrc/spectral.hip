@@ -193,28 +193,61 @@ __global__ __launch_bounds__(SN_THREADS) void spectral_norm_multi_fwd_kernel(con
 struct SnBwdDesc {
     long long R, Cn, uses, out_off, g_off, dw_off;
 };
-__global__ __launch_bounds__(SN_THREADS) void spectral_norm_multi_bwd_kernel(const SnBwdDesc *__restrict__ desc,
-                                                                             const float *__restrict__ g,
-                                                                             const float *__restrict__ out,
-                                                                             float *__restrict__ dw) {
+// Two launches, each spread over SNB_CH row chunks per weight (one workgroup per weight, as the
+// forward has to be, pulled the whole 6 x 3 passes over a 0.5 MB weight through ONE CU: 313 us
+// at the end of the discriminator update's backward chain):
+//   dots : partial <G_t, Wsn_t> of every (weight, use, row chunk)  -> dots[(m*maxu + t)*SNB_CH + c]
+//   apply: dW[e] = sum_t (G_t[e] - dot_t u_t[i] v_t[j]) / sigma_t, dot_t = the SNB_CH partials summed in
+//          fixed order; each element is accumulated in a register over the uses and written once.
+constexpr int SNB_CH = 8;
+
+__global__ __launch_bounds__(SN_THREADS) void spectral_norm_multi_bwd_dots_kernel(
+    const SnBwdDesc *__restrict__ desc, const float *__restrict__ g, const float *__restrict__ out, int maxu,
+    float *__restrict__ dots) {
     __shared__ float scratch[16];
-    const SnBwdDesc d = desc[blockIdx.x];
-    const int R = (int)d.R, Cn = (int)d.Cn, tid = threadIdx.x;
+    const int m = blockIdx.y, c = blockIdx.x, tid = threadIdx.x;
+    const SnBwdDesc d = desc[m];
+    const int R = (int)d.R, Cn = (int)d.Cn;
     const size_t n = (size_t)R * Cn;
-    float *dW = dw + d.dw_off;
-    for (size_t e = tid; e < n; e += SN_THREADS) dW[e] = 0.0f;
+    const int r0 = (int)((long long)R * c / SNB_CH), r1 = (int)((long long)R * (c + 1) / SNB_CH);
+    const size_t e0 = (size_t)r0 * Cn, e1 = (size_t)r1 * Cn;
     for (int t = 0; t < (int)d.uses; ++t) {
         const float *G = g + d.g_off + (size_t)t * n;
         const float *o = out + d.out_off + (size_t)t * sn_stride(R, Cn);
-        const float *ou = o + n, *ov = ou + R;
-        const float sigma = ov[Cn];
         float dot = 0.0f;
-        for (size_t e = tid; e < n; e += SN_THREADS) dot += G[e] * o[e];
+        for (size_t e = e0 + tid; e < e1; e += SN_THREADS) dot += G[e] * o[e];
         dot = block_sum(dot, scratch);
-        for (size_t e = tid; e < n; e += SN_THREADS) {
-            const int i = (int)(e / Cn), j = (int)(e - (size_t)i * Cn);
-            dW[e] += (G[e] - dot * ou[i] * ov[j]) / sigma;
+        if (tid == 0) dots[((size_t)m * maxu + t) * SNB_CH + c] = dot;
+        __syncthreads();
+    }
+}
+
+__global__ __launch_bounds__(SN_THREADS) void spectral_norm_multi_bwd_apply_kernel(
+    const SnBwdDesc *__restrict__ desc, const float *__restrict__ g, const float *__restrict__ out, int maxu,
+    const float *__restrict__ dots, float *__restrict__ dw) {
+    __shared__ float sdot[64], ssig[64];
+    const int m = blockIdx.y, c = blockIdx.x, tid = threadIdx.x;
+    const SnBwdDesc d = desc[m];
+    const int R = (int)d.R, Cn = (int)d.Cn, U = (int)d.uses;
+    const size_t n = (size_t)R * Cn;
+    for (int t = tid; t < U; t += SN_THREADS) {
+        const float *pd = dots + ((size_t)m * maxu + t) * SNB_CH;
+        float s = 0.0f;
+        for (int cc = 0; cc < SNB_CH; ++cc) s += pd[cc];
+        sdot[t] = s;
+        ssig[t] = out[d.out_off + (size_t)t * sn_stride(R, Cn) + n + R + Cn];
+    }
+    __syncthreads();
+    const int r0 = (int)((long long)R * c / SNB_CH), r1 = (int)((long long)R * (c + 1) / SNB_CH);
+    float *dW = dw + d.dw_off;
+    for (size_t e = (size_t)r0 * Cn + tid; e < (size_t)r1 * Cn; e += SN_THREADS) {
+        const int i = (int)(e / Cn), j = (int)(e - (size_t)i * Cn);
+        float acc = 0.0f;
+        for (int t = 0; t < U; ++t) {
+            const float *o = out + d.out_off + (size_t)t * sn_stride(R, Cn);
+            acc += (g[d.g_off + (size_t)t * n + e] - sdot[t] * o[n + i] * o[n + R + j]) / ssig[t];
         }
+        dW[e] = acc;
     }
 }
 
@@ -234,12 +267,19 @@ extern "C" int tpg_spectral_norm_multi_fwd(const void *desc, int M, int max_rc, 
     return TPG_OK;
 }
 
-extern "C" int tpg_spectral_norm_multi_bwd(const void *desc, int M, const float *g, const float *out, float *dw,
-                                           void *stream) {
-    if (M < 0 || !desc || !g || !out || !dw) return TPG_ERR_ARG;
+extern "C" long long tpg_spectral_norm_multi_bwd_scratch(int M, int max_uses) {
+    return (long long)M * max_uses * SNB_CH;          // floats
+}
+
+extern "C" int tpg_spectral_norm_multi_bwd(const void *desc, int M, int max_uses, const float *g, const float *out,
+                                           float *dw, float *scratch, void *stream) {
+    if (M < 0 || max_uses < 1 || max_uses > 64 || !desc || !g || !out || !dw || !scratch) return TPG_ERR_ARG;
     if (M == 0) return TPG_OK;
-    hipLaunchKernelGGL(spectral_norm_multi_bwd_kernel, dim3(M), dim3(SN_THREADS), 0, tpg_stream(stream),
-                       static_cast<const SnBwdDesc *>(desc), g, out, dw);
+    const SnBwdDesc *dd = static_cast<const SnBwdDesc *>(desc);
+    hipLaunchKernelGGL(spectral_norm_multi_bwd_dots_kernel, dim3(SNB_CH, M), dim3(SN_THREADS), 0, tpg_stream(stream),
+                       dd, g, out, max_uses, scratch);
+    hipLaunchKernelGGL(spectral_norm_multi_bwd_apply_kernel, dim3(SNB_CH, M), dim3(SN_THREADS), 0,
+                       tpg_stream(stream), dd, g, out, max_uses, scratch, dw);
     TPG_RETURN_IF_LAUNCH_FAILED();
     return TPG_OK;
 }

@@ -355,6 +355,7 @@ class HipBackend:
         key = tuple(t.data_ptr() for t in (*Ws, *us, *vs)) + tuple(uses)
         plan = self._sn_plans.get(key)
         if plan is None:
+            _need(max(int(n) for n in uses) <= 64, "at most 64 uses of one spectrally-normalised weight per forward")
             dev = Ws[0].device
             fwd, bwd, layout, goffs, dwoffs = [], [], [], [], []
             out_total = g_total = dw_total = 0
@@ -371,7 +372,8 @@ class HipBackend:
                 dw_total += R * Cn
             plan = dict(fwd=torch.tensor(fwd, dtype=torch.int64).to(dev), bwd=torch.tensor(bwd, dtype=torch.int64).to(dev),
                         layout=layout, goffs=goffs, dwoffs=dwoffs, out_total=out_total, g_total=g_total,
-                        dw_total=dw_total, max_rc=max(W.shape[0] + W.shape[1] for W in Ws), M=len(Ws))
+                        dw_total=dw_total, max_rc=max(W.shape[0] + W.shape[1] for W in Ws), M=len(Ws),
+                        max_uses=max(int(n) for n in uses))
             self._sn_plans[key] = plan
         return plan
 
@@ -386,8 +388,11 @@ class HipBackend:
 
     def spectral_norm_multi_bwd(self, out, plan, gflat):
         dw = torch.empty(plan["dw_total"], dtype=torch.float32, device=out.device)
-        self._call("tpg_spectral_norm_multi_bwd", "spectral_norm_bwd", 4 * (2 * plan["g_total"] + plan["dw_total"]),
-                   out, _ptr(plan["bwd"]), plan["M"], _ptr(gflat), _ptr(out), _ptr(dw))
+        maxu = plan["max_uses"]
+        scratch = torch.empty(self.lib.tpg_spectral_norm_multi_bwd_scratch(plan["M"], maxu), dtype=torch.float32,
+                              device=out.device)
+        self._call("tpg_spectral_norm_multi_bwd", "spectral_norm_bwd", 4 * (3 * plan["g_total"] + plan["dw_total"]),
+                   out, _ptr(plan["bwd"]), plan["M"], maxu, _ptr(gflat), _ptr(out), _ptr(dw), _ptr(scratch))
         return dw
 
 
