@@ -416,8 +416,11 @@ class GraphedFluidStep:
     def __call__(self, lowres_pos_lst, highres_pos_lst, n_iter, freeze_D=False):
         """Same contract as the eager step function (without velocities); returns its loss dict."""
         update_D = n_iter % 2 == 0 and not freeze_D
-        if n_iter <= self.EAGER_UNTIL:
-            return self._eager(lowres_pos_lst, highres_pos_lst, n_iter, freeze_D)
+        same_shapes = (len(lowres_pos_lst) == len(self.low) and len(highres_pos_lst) == len(self.high)
+                       and all(a.shape == b.shape for a, b in zip(lowres_pos_lst, self.low))
+                       and all(a.shape == b.shape for a, b in zip(highres_pos_lst, self.high)))
+        if n_iter <= self.EAGER_UNTIL or not same_shapes:      # graphs are shape-specialised (a ragged last
+            return self._eager(lowres_pos_lst, highres_pos_lst, n_iter, freeze_D)   # batch takes the eager step)
         np_state, cpu_rng = np.random.get_state(), torch.get_rng_state()
         cuda_rng = torch.cuda.get_rng_state(self.dev)
         self._stage_host_draws(update_D)

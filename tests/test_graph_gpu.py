@@ -76,6 +76,10 @@ def test_graph_replay_equals_eager(segmented):
     # later steps are not comparable number for number (an untrained generator's near-coincident
     # points make FPS / kNN decisions chaotic under 1e-7 differences); the replay must simply keep
     # working in the static regime, for G-only (odd) and G+D (even) iterations alike
+    # another batch size than the captured one: the eager step, not a replay on stale shapes
+    small = fluid_clip(2, 1024, 8, 3, seed=9, device=dev)
+    lg = stepper(small[0], small[1], 12)
+    assert all(np.isfinite(v) for v in lg.values())
     for it, (low, high) in zip((13, 14, 15), (clips[1], clips[0], clips[1])):
         lg = stepper(low, high, it)       # (a large SGD step may close the gate: then this is the fallback)
         assert all(np.isfinite(v) for v in lg.values())
