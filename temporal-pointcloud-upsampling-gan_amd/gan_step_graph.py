@@ -35,7 +35,6 @@ Multi-GPU: with `sync.world_size > 1` the step is captured as two graphs (`_phas
 `_phase_apply`) and ONE flat gradient all-reduce over the three networks runs eagerly between
 them (RCCL calls are kept out of capture).
 """
-import contextlib
 import os
 
 import numpy as np
