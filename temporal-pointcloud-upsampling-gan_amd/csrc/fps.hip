@@ -188,9 +188,17 @@ extern "C" int tpg_fps_start_f32(const float *xyz, const int32_t *start, int ski
     hipStream_t st = tpg_stream(stream);
     if (N <= 256) fps_go<64, 4>(xyz, B, N, m, idx, start, skip_origin, st);
     else if (N <= 512) fps_go<128, 4>(xyz, B, N, m, idx, start, skip_origin, st);
+#if defined(TPG_FPS_1024_BLOCK)
+    else if (N <= 1024) fps_go<TPG_FPS_1024_BLOCK, 1024 / TPG_FPS_1024_BLOCK>(xyz, B, N, m, idx, start, skip_origin, st);
+#else
     else if (N <= 1024) fps_go<256, 4>(xyz, B, N, m, idx, start, skip_origin, st);
+#endif
     else if (N <= 2048) fps_go<512, 4>(xyz, B, N, m, idx, start, skip_origin, st);
+#if defined(TPG_FPS_4096_BLOCK)
+    else if (N <= 4096) fps_go<TPG_FPS_4096_BLOCK, 4096 / TPG_FPS_4096_BLOCK>(xyz, B, N, m, idx, start, skip_origin, st);
+#else
     else if (N <= 4096) fps_go<1024, 4>(xyz, B, N, m, idx, start, skip_origin, st);
+#endif
     else if (N <= 8192) fps_go<1024, 8>(xyz, B, N, m, idx, start, skip_origin, st);
     else if (N <= 16384) fps_go<1024, 16>(xyz, B, N, m, idx, start, skip_origin, st);
     else {

@@ -42,7 +42,7 @@ import torch
 
 from .gan_step import _frozen, _autocast, _set_dummy_check, _NoSync, get_rotation_matrix, tempo_gan_step
 from .losses import tpugan_sr_loss
-from .set_abstraction import _plan_tensors, run_index_plan
+from .set_abstraction import _plan_tensors, attach_plan_inverses, run_index_plan
 
 
 def _state_tensors(modules, optims):
@@ -151,11 +151,40 @@ class GraphedFluidStep:
         self._dev_f.copy_(self._host_f)
 
     # ------------------------------------------------------------------ step body (capturable)
-    def _plan(self, make, which):
-        """(plan, join) for a discriminator forward; inline (plan None) when plans are disabled."""
+    def _fake_plans(self, update_D, fake_s_in, fake_t_in, make_fake_s, make_fake_t):
+        """Index plans of every discriminator forward that looks at generated clouds, started on
+        the two side streams as soon as those clouds exist: the generator step's forwards
+        (`fake_s_in`, `fake_t_in`) and, if the discriminators are updated, the update's fake batch
+        (`make_fake_*()`, built on the side stream) merged with the real batch's plan.  The
+        searches of both forwards of a discriminator are launched together (`index_plans`): their
+        FPS rounds then cost the latency of one.  -> join_fs, join_ft, plan_fs, plan_ft for the
+        generator step; the update's clouds and plans go to self._keep."""
+        Ds, Dt, opt, k = self.Ds, self.Dt, self.opt, self._keep
         if not self.use_plans:
-            return None, (lambda: None)
-        return run_index_plan(make, self.sides[which])
+            if update_D:
+                k["fake_s"], k["plan_s"], k["fakes"], k["plan_t"] = make_fake_s(), None, make_fake_t(), None
+            return (lambda: None), (lambda: None), None, None
+        if not update_D:
+            plan_fs, join_fs = run_index_plan(lambda: Ds.index_plan(fake_s_in), self.sides[1])
+            plan_ft, join_ft = run_index_plan(lambda: Dt.merge_plans(Dt.index_plans([fake_t_in], opt.R)), self.sides[0])
+            return join_fs, join_ft, plan_fs, plan_ft
+
+        def both_s():
+            fake_s = make_fake_s()
+            mine, theirs = Ds.index_plans([fake_s_in, fake_s])
+            return fake_s, attach_plan_inverses(mine), theirs
+
+        def both_t():
+            fakes = make_fake_t()
+            mine, theirs = Dt.index_plans([fake_t_in, fakes], opt.R)
+            return fakes, Dt.merge_plans([mine]), theirs       # (ONE pass: frames and pairs still run as segments)
+        (k["fake_s"], plan_fs, upd_s), join_fs = run_index_plan(both_s, self.sides[1])
+        (k["fakes"], plan_ft, upd_t), join_ft = run_index_plan(both_t, self.sides[0])
+        # fake and real batch run as segments of ONE discriminator pass: one plan for both, put
+        # together after the generator step's plan is out (same stream as the real batch's plan)
+        k["plan_s"], _ = run_index_plan(lambda: Ds.merge_plans([upd_s, k["plan_true_s"]]), self.sides[1])
+        k["plan_t"], _ = run_index_plan(lambda: Dt.merge_plans([upd_t, k["plan_true_t"]]), self.sides[0])
+        return join_fs, join_ft, plan_fs, plan_ft
 
     def _join_sides(self, stream=None):
         stream = stream or torch.cuda.current_stream(self.dev)
@@ -172,11 +201,11 @@ class GraphedFluidStep:
             # the real clouds exist already: their (rotated) copies and index plans start now
             def real_t():
                 trues = [torch.matmul(h, self.rot_true_t[f]) for f, h in enumerate(high)]
-                return trues, (Dt.index_plan(trues, opt.R) if self.use_plans else None)
+                return trues, (Dt.index_plans([trues], opt.R)[0] if self.use_plans else None)
 
             def real_s():
                 true_s = torch.bmm(high[1], self.rot_true_s)
-                return true_s, (Ds.index_plan(true_s) if self.use_plans else None)
+                return true_s, (Ds.index_plans([true_s])[0] if self.use_plans else None)
             (k["trues"], k["plan_true_t"]), _ = run_index_plan(real_t, self.sides[0])
             (k["true_s"], k["plan_true_s"]), _ = run_index_plan(real_s, self.sides[1])
         # The generator has no cross-sample coupling (no BatchNorm): its T per-frame calls
@@ -191,10 +220,7 @@ class GraphedFluidStep:
         edge, mask = edges[0], masks[0]
         pred_c, padded_c, keep_c = G.expand_pos_static(low[1], edge, mask)
         fake_s_in = padded_c.index_select(1, self.perm_c).float()
-        plan_fs, join_fs = self._plan(lambda: Ds.index_plan(fake_s_in), 1)
-        position_loss, cd, ml = tpugan_sr_loss(100., high[1], pred_c.float(), low[1], mask.float(),
-                                               opt.cutoff / self.fd, 11)
-        viol = ~(ml.reshape(()) < 0.1) | ~keep_c                   # NaN counts as a violation
+        viol = ~keep_c
         with _frozen(Ds, Dt), _autocast(self.amp, self.dev):
             pred_lst = [None] * self.T
             pred_lst[1] = padded_c
@@ -204,24 +230,14 @@ class GraphedFluidStep:
                 pred_lst[f] = padded.index_select(1, self.perm_f[i])
                 last_padded = padded
             fake_t_in = [p.float() for p in pred_lst]
-            # (merged plan of ONE pass: the frames and frame pairs still run as segments)
-            plan_ft, join_ft = self._plan(lambda: Dt.merge_plans([Dt.index_plan(fake_t_in, opt.R)]), 0)   # overlaps D_spatial
-            if update_D:
-                # fake and real batch run as segments of ONE discriminator pass: one plan for both
-                # (same stream as the real plan it is merged with)
-                def fake_t():
-                    fakes = [torch.matmul(p.detach(), self.rot_fake_t[f]) for f, p in enumerate(fake_t_in)]
-                    if not self.use_plans:
-                        return fakes, None
-                    return fakes, Dt.merge_plans([Dt.index_plan(fakes, opt.R), k["plan_true_t"]])
-
-                def fake_s_():
-                    fake_s = torch.bmm(last_padded.detach().float(), self.rot_fake_s)
-                    if not self.use_plans:
-                        return fake_s, None
-                    return fake_s, Ds.merge_plans([Ds.index_plan(fake_s), k["plan_true_s"]])
-                (k["fakes"], k["plan_t"]), _ = run_index_plan(fake_t, self.sides[0])
-                (k["fake_s"], k["plan_s"]), _ = run_index_plan(fake_s_, self.sides[1])
+        join_fs, join_ft, plan_fs, plan_ft = self._fake_plans(
+            update_D, fake_s_in, fake_t_in,
+            lambda: torch.bmm(last_padded.detach().float(), self.rot_fake_s),
+            lambda: [torch.matmul(p.detach(), self.rot_fake_t[f]) for f, p in enumerate(fake_t_in)])
+        position_loss, cd, ml = tpugan_sr_loss(100., high[1], pred_c.float(), low[1], mask.float(),
+                                               opt.cutoff / self.fd, 11)
+        viol = viol | ~(ml.reshape(()) < 0.1)                      # NaN counts as a violation
+        with _frozen(Ds, Dt), _autocast(self.amp, self.dev):
             join_fs()
             fake = Ds(fake_s_in, plan=plan_fs)
             spatial_loss = (0.5 * (fake.float() - lab[2]) ** 2).mean()
@@ -504,35 +520,22 @@ class GraphedActionStep(GraphedFluidStep):
         order = [1] + others
         if update_D:                       # the real clouds exist already: their index plans start now
             (k["trues"], k["plan_true_t"]), _ = run_index_plan(
-                lambda: (list(high), Dt.index_plan(list(high), opt.R) if self.use_plans else None), self.sides[0])
+                lambda: (list(high), Dt.index_plans([list(high)], opt.R)[0] if self.use_plans else None), self.sides[0])
             (k["true_s"], k["plan_true_s"]), _ = run_index_plan(
-                lambda: (high[1], Ds.index_plan(high[1]) if self.use_plans else None), self.sides[1])
+                lambda: (high[1], Ds.index_plans([high[1]])[0] if self.use_plans else None), self.sides[1])
         with _frozen(Ds, Dt), _autocast(self.amp, self.dev):
             edge_all = G.body(torch.cat([low[f] for f in order], 0))
             edges = edge_all.reshape(len(order), self.B, *edge_all.shape[1:]).unbind(0)
             pred_c = G.expand_pos(low[1], edges[0]).float()
             fake_s_in = pred_c.index_select(1, self.perm_sg)
-            plan_fs, join_fs = self._plan(lambda: Ds.index_plan(fake_s_in), 1)
-            position_loss, cd, _ = tpugan_sr_loss(0, high[1], pred_c, 0., 0., 0., 0)
             pred_lst = [None] * self.T
             pred_lst[1] = pred_c.index_select(1, self.perm_c)
             for i, f in enumerate(others):
                 pred_lst[f] = G.expand_pos(low[f], edges[i + 1]).float().index_select(1, self.perm_f[i])
-            plan_ft, join_ft = self._plan(lambda: Dt.merge_plans([Dt.index_plan(pred_lst, opt.R)]), 0)
-            if update_D:
-                def fake_t():
-                    fakes = [p.detach() for p in pred_lst]
-                    if not self.use_plans:
-                        return fakes, None
-                    return fakes, Dt.merge_plans([Dt.index_plan(fakes, opt.R), k["plan_true_t"]])
-
-                def fake_s_():
-                    fake_s = pred_c.detach().index_select(1, self.perm_sd)
-                    if not self.use_plans:
-                        return fake_s, None
-                    return fake_s, Ds.merge_plans([Ds.index_plan(fake_s), k["plan_true_s"]])
-                (k["fakes"], k["plan_t"]), _ = run_index_plan(fake_t, self.sides[0])
-                (k["fake_s"], k["plan_s"]), _ = run_index_plan(fake_s_, self.sides[1])
+            join_fs, join_ft, plan_fs, plan_ft = self._fake_plans(
+                update_D, fake_s_in, pred_lst, lambda: pred_c.detach().index_select(1, self.perm_sd),
+                lambda: [p.detach() for p in pred_lst])
+            position_loss, cd, _ = tpugan_sr_loss(0, high[1], pred_c, 0., 0., 0., 0)
             join_fs()
             fake = Ds(fake_s_in, plan=plan_fs)
             spatial_loss = (0.5 * (fake.float() - lab[2]) ** 2).mean()

@@ -309,17 +309,18 @@ class _PointnetSAModuleBase(nn.Module):
             centres = replace_dummy_centres(xyz, centres)
         return centres
 
-    def index_level(self, xyz):
+    def index_level(self, xyz, inverse=True):
         """All index-only work of this level for detached clouds xyz (B,N,3):
         -> (centres (B,S) int32, new_xyz (B,S,3) detached, idx (B,S,ns) int32).
         It depends on coordinates only, so a caller may run it ahead of time / on another stream
-        (see `index_plan` of the discriminators) and hand the result to `forward_rows`."""
+        (see `index_plan` of the discriminators) and hand the result to `forward_rows`.
+        inverse=False leaves the inverted index to whoever regroups the lists (`merge_plans`)."""
         xyz = xyz.detach().float().contiguous()
         centres = self.sample_centres(xyz)
         new_xyz = ops.gather_operation(xyz.transpose(1, 2).contiguous(), centres).transpose(1, 2).contiguous()
         g = self.groupers[0]
-        idx = ops.ball_query(g.radius, g.nsample, xyz, new_xyz)
-        if rows_first():
+        idx = _sources(ops.ball_query(g.radius, g.nsample, xyz, new_xyz), xyz.shape[1])
+        if inverse and rows_first():
             ops.attach_inverse(idx, xyz.shape[1])       # for the backward of the row gather
         return centres, new_xyz, idx
 
@@ -570,12 +571,13 @@ class FlowModule(nn.Module):
                 spec = (hidden_feat, [hidden_feat, hidden_feat // 2, hidden_feat])
             self.flow_emb_layers.append(FlowEmbedding(spec[0], spec[1], sn=sn))
 
-    def pair_indices(self, pos_rows_lst, cutoff):
+    def pair_indices(self, pos_rows_lst, cutoff, inverse=True):
         """Neighbour lists of the frame pairs (l, l+1): positions only, shared by every depth."""
-        pairs = [ball_query_wrapper(cutoff, FlowEmbedding.NSAMPLE, pos_rows_lst[l].detach(),
-                                    pos_rows_lst[l + 1].detach()).to(torch.int32).contiguous()
+        pairs = [_sources(ball_query_wrapper(cutoff, FlowEmbedding.NSAMPLE, pos_rows_lst[l].detach(),
+                                             pos_rows_lst[l + 1].detach()).to(torch.int32).contiguous(),
+                          pos_rows_lst[l + 1].shape[1])
                  for l in range(len(pos_rows_lst) - 1)]
-        if rows_first():
+        if inverse and rows_first():
             for l, idx in enumerate(pairs):               # for the backward of the row gather
                 ops.attach_inverse(idx, pos_rows_lst[l + 1].shape[1])
         return pairs
@@ -649,6 +651,27 @@ def _head_fp32(fc_layers, x):
         return x
 
 
+def _sources(idx, n_src):
+    """Remember on a neighbour list how many source rows it indexes (merge_plans needs it)."""
+    idx._tpg_nsrc = int(n_src)
+    return idx
+
+
+def _cut(idx, lo, hi):
+    """Clouds lo..hi of a neighbour list (a view: the clouds are the leading, contiguous axis)."""
+    return _sources(idx[lo:hi], idx._tpg_nsrc)
+
+
+def attach_plan_inverses(plan):
+    """Give every ball-query list of a per-pass plan of `index_plans` its inverted index, so the
+    plan can go to `forward(..., plan=)` directly instead of through `merge_plans`."""
+    for _, idx in plan["sa"]:
+        ops.attach_inverse(idx, idx._tpg_nsrc)
+    for idx in plan.get("flow", []):
+        ops.attach_inverse(idx, idx._tpg_nsrc)
+    return plan
+
+
 def run_index_plan(make_plan, stream):
     """Run `make_plan()` (an `index_plan` call, possibly preceded by cheap tensor prep) on
     `stream`, forked from the current stream; returns (result, join) where `join()` makes the
@@ -699,6 +722,24 @@ class _TempoDis(nn.Module):
                                               self.flow_radius_scale * cutoff)
         return {"sa": [(c0, i0), (c1, i1)], "flow": pairs}
 
+    def index_plans(self, pos_lsts, cutoff):
+        """[index_plan(p, cutoff) for p in pos_lsts] (same shapes) with every search launched ONCE
+        for all passes: furthest point sampling is npoint-1 dependent rounds on one workgroup per
+        cloud, so on a 256-CU part the passes' clouds cost the rounds of one pass.  Every search is
+        per cloud, so the lists are the ones separate calls give.  The per-pass plans come without
+        inverted indices: hand them to `merge_plans` (or `attach_plan_inverses`)."""
+        NP, T, B = len(pos_lsts), len(pos_lsts[0]), pos_lsts[0][0].shape[0]
+        xyz = torch.cat([p.detach().float() for pos_lst in pos_lsts for p in pos_lst], 0)   # pass-major
+        c0, x1, i0 = self.coarse_graining_module[0].index_level(xyz, inverse=False)
+        c1, x2, i1 = self.coarse_graining_module[1].index_level(x1, inverse=False)
+        frames = x2.view(NP, T, B, *x2.shape[1:])
+        pairs = self.flow_module.pair_indices([frames[:, t].reshape(NP * B, *x2.shape[1:]) for t in range(T)],
+                                              self.flow_radius_scale * cutoff, inverse=False)
+        n = T * B
+        return [{"sa": [(c0[p * n:(p + 1) * n], _cut(i0, p * n, (p + 1) * n)),
+                        (c1[p * n:(p + 1) * n], _cut(i1, p * n, (p + 1) * n))],
+                 "flow": [_cut(pr, p * B, (p + 1) * B) for pr in pairs]} for p in range(NP)]
+
     def _levels(self, pos_lst, feat_lst, plan=None):
         feats0 = list(feat_lst) if feat_lst is not None else list(pos_lst)
         sa = plan["sa"] if plan is not None else (None, None)
@@ -719,14 +760,14 @@ class _TempoDis(nn.Module):
 
     def merge_plans(self, plans):
         """Index plans of successive forwards (same shapes) -> the plan of `forward_passes`."""
-        n0 = plans[0]["sa"][0][1]._tpg_inverse[0]
-        n1 = plans[0]["sa"][1][1]._tpg_inverse[0]
+        n0 = plans[0]["sa"][0][1]._tpg_nsrc
+        n1 = plans[0]["sa"][1][1]._tpg_nsrc
         sa = []
         for l, n_src in ((0, n0), (1, n1)):
             c = torch.cat([p["sa"][l][0] for p in plans], 0)
             i = ops.attach_inverse(torch.cat([p["sa"][l][1] for p in plans], 0).contiguous(), n_src)
             sa.append((c, i))
-        n2 = plans[0]["flow"][0]._tpg_inverse[0]
+        n2 = plans[0]["flow"][0]._tpg_nsrc
         return {"sa": sa, "flow_depth": self.flow_module.depth_indices([p["flow"] for p in plans], n2)}
 
     def forward_passes(self, pos_lsts, cutoff, plan=None):
@@ -807,7 +848,7 @@ class _SpatialDis(nn.Module):
         """Index plans of successive forwards (same shapes) -> the plan of `forward_passes`."""
         sa = []
         for l in range(len(self.coarse_graining_module)):
-            n_src = plans[0]["sa"][l][1]._tpg_inverse[0]
+            n_src = plans[0]["sa"][l][1]._tpg_nsrc
             c = torch.cat([p["sa"][l][0] for p in plans], 0)
             sa.append((c, ops.attach_inverse(torch.cat([p["sa"][l][1] for p in plans], 0).contiguous(), n_src)))
         return {"sa": sa}
@@ -828,6 +869,16 @@ class _SpatialDis(nn.Module):
                 pos, feature = sa.forward_rows_stacked(pos, pos if feature is None else feature, NP, plan["sa"][l])
             pooled = self.SA_pooling.forward_rows_pool_stacked(pos, feature, NP)
             return [_head_fp32(self.fc_layers, h) for h in pooled.view(NP, B, -1).unbind(0)]
+
+    def index_plans(self, pos_list):
+        """[index_plan(p) for p in pos_list] with every search launched once for all passes (see
+        _TempoDis.index_plans); per-pass plans without inverted indices."""
+        NP, B = len(pos_list), pos_list[0].shape[0]
+        xyz, levels = torch.cat([p.detach().float() for p in pos_list], 0), []
+        for sa in self.coarse_graining_module:
+            c, xyz, i = sa.index_level(xyz, inverse=False)
+            levels.append((c, i))
+        return [{"sa": [(c[p * B:(p + 1) * B], _cut(i, p * B, (p + 1) * B)) for c, i in levels]} for p in range(NP)]
 
     def index_plan(self, pos):
         """FPS centres + ball-query lists of every level for the clouds `pos` (coordinates only)."""
