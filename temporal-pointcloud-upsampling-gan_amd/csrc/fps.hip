@@ -10,12 +10,16 @@
 //     broadcast read of the last selected point from an LDS copy of the cloud;
 //   * the round is branch-free: running distances live as float bits compared
 //     as ints, with -1.0f marking points that are never eligible;
-//   * arg-max with ties to the smallest index (the canonical rule) = integer
-//     max of the value, then min over the indices attaining it: two 32-bit DPP
-//     wave reductions (no LDS traffic), then ONE barrier per round: each wave
-//     drops its (value, index) into a double-buffered LDS slot and every wave
-//     re-reduces the <=16 slots redundantly, so no second barrier and no
-//     broadcast step are needed;
+//   * arg-max with ties to the smallest index (the canonical rule): a thread
+//     owns PPT CONSECUTIVE points, so inside a lane the first strict maximum,
+//     inside a wave the lowest lane and among the waves the lowest wave hold
+//     the smallest index.  One 32-bit DPP max reduction of the value, then
+//     ballot(value == max) -> first set lane -> v_readlane of its index: the
+//     index never goes through a reduction of its own.  ONE barrier per
+//     round: each wave drops its (value, index) into a double-buffered LDS
+//     slot and every wave re-reduces the <=16 slots redundantly, so no second
+//     barrier and no broadcast step are needed.  (A round is VALU-issue bound
+//     on its one CU: ~80 wave instructions x 16 waves.)
 //   * clouds of <=256 points run in a single wave with no barrier at all.
 // Callers batch frames x {fake,true} x batch into B so that B workgroups run
 // concurrently (the reference issues one launch per frame per cloud batch).
@@ -39,11 +43,10 @@ __global__ __launch_bounds__(BLOCK) void fps_kernel(const float *__restrict__ xy
                                                     const int32_t *__restrict__ start, int skip_origin) {
     extern __shared__ __attribute__((aligned(16))) float fps_smem[];
     constexpr int NW = BLOCK / 64;
-    // layout: [2][16] (value,index) slots (256 B), then SoA copy of the cloud (USE_LDS)
+    // layout: [2][16] (value,index) slots (256 B), then a copy of the cloud (USE_LDS): xyz of a
+    // point side by side, so the winner's coordinates are one address and three offsets
     int2 *slots = reinterpret_cast<int2 *>(fps_smem);
-    float *sx = fps_smem + 64;
-    float *sy = sx + N;
-    float *sz = sy + N;
+    float *sp = fps_smem + 64;
 
     const int tid = threadIdx.x;
     const int lane = tid & 63;
@@ -51,10 +54,11 @@ __global__ __launch_bounds__(BLOCK) void fps_kernel(const float *__restrict__ xy
     const float *x = xyz + (size_t)blockIdx.x * N * 3;
     int32_t *out = idx + (size_t)blockIdx.x * m;
 
-    float px[PPT], py[PPT], pz[PPT], tp[PPT];
+    float px[PPT], py[PPT], pz[PPT];
+    int tp[PPT];                          // running min distance, as float bits (see above)
 #pragma unroll
     for (int t = 0; t < PPT; ++t) {
-        const int k = tid + t * BLOCK;
+        const int k = tid * PPT + t;
         const bool in = k < N;
         px[t] = in ? x[(size_t)k * 3 + 0] : 0.0f;
         py[t] = in ? x[(size_t)k * 3 + 1] : 0.0f;
@@ -62,8 +66,8 @@ __global__ __launch_bounds__(BLOCK) void fps_kernel(const float *__restrict__ xy
         float mag = px[t] * px[t];
         mag = mag + py[t] * py[t];
         mag = mag + pz[t] * pz[t];
-        tp[t] = (in && (!skip_origin || mag > 1e-3f)) ? 1e10f : -1.0f;
-        if (USE_LDS && in) { sx[k] = px[t]; sy[k] = py[t]; sz[k] = pz[t]; }
+        tp[t] = __float_as_int((in && (!skip_origin || mag > 1e-3f)) ? 1e10f : -1.0f);
+        if (USE_LDS && in) { sp[3 * k] = px[t]; sp[3 * k + 1] = py[t]; sp[3 * k + 2] = pz[t]; }
     }
     int old = start ? tpg_clamp_idx(start[blockIdx.x], N) : 0;       // pointnet2: always point 0
     if (tid == 0) out[0] = old;
@@ -71,7 +75,7 @@ __global__ __launch_bounds__(BLOCK) void fps_kernel(const float *__restrict__ xy
 
     for (int j = 1; j < m; ++j) {
         float ox, oy, oz;
-        if (USE_LDS) { ox = sx[old]; oy = sy[old]; oz = sz[old]; }
+        if (USE_LDS) { ox = sp[3 * old]; oy = sp[3 * old + 1]; oz = sp[3 * old + 2]; }
         else { ox = x[(size_t)old * 3]; oy = x[(size_t)old * 3 + 1]; oz = x[(size_t)old * 3 + 2]; }
 
         int best = __float_as_int(-1.0f);
@@ -79,26 +83,27 @@ __global__ __launch_bounds__(BLOCK) void fps_kernel(const float *__restrict__ xy
 #pragma unroll
         for (int t = 0; t < PPT; ++t) {
             const float d = tpg_sq3(px[t], py[t], pz[t], ox, oy, oz);
-            const float d2 = d < tp[t] ? d : tp[t];
-            tp[t] = d2;
-            const int b2 = __float_as_int(d2);
+            // min on the bits: d >= +0 (NaN bits are a large int: the running value stays, as in
+            // `d < tp ? d : tp`), and -1.0f is a negative int that stays the minimum
+            const int b2 = min(__float_as_int(d), tp[t]);
+            tp[t] = b2;
             const bool up = b2 > best;            // strict: first (smallest) index wins inside a lane
             best = up ? b2 : best;
-            besti = up ? tid + t * BLOCK : besti;
+            besti = up ? tid * PPT + t : besti;
         }
-        // arg-max with ties to the smallest index = max of the value, then min over the indices
-        // that attain it: two 32-bit DPP reductions.
-        int mx = tpg_wave_max_i32(best);
-        unsigned bi = tpg_wave_min_u32(best == mx ? (unsigned)besti : 0xffffffffu);
+        // the value's max, then the index of the FIRST lane that attains it (lower lane <=> lower
+        // indices): the mask is never empty, the maximum is somebody's value
+        int mx = tpg_wave_max_i32_rows(best);
+        int bi = __builtin_amdgcn_readlane(besti, __builtin_ctzll(__ballot(best == mx)));
         if constexpr (NW > 1) {
             int2 *slot = slots + (j & 1) * 16;
-            if (lane == 0) slot[wave] = make_int2(mx, (int)bi);
+            if (lane == 0) slot[wave] = make_int2(mx, bi);
             __syncthreads();
             const int2 sv = lane < NW ? slot[lane] : make_int2((int)0x80000000, 0);
-            mx = tpg_row16_max_i32(sv.x);
-            bi = tpg_row16_min_u32(sv.x == mx ? (unsigned)sv.y : 0xffffffffu);
+            mx = tpg_row16_max_i32(sv.x);         // every slot value is >= bits(-1.0f) > INT_MIN
+            bi = __builtin_amdgcn_readlane(sv.y, __builtin_ctzll(__ballot(sv.x == mx)));
         }
-        old = mx >= 0 ? (int)bi : 0;              // mx < 0 <=> no eligible point at all
+        old = mx >= 0 ? bi : 0;                   // mx < 0 <=> no eligible point at all
         if (tid == 0) out[j] = old;
     }
 }
@@ -186,21 +191,30 @@ extern "C" int tpg_fps_start_f32(const float *xyz, const int32_t *start, int ski
     if (B == 0) return TPG_OK;
     if (!xyz || !idx) return TPG_ERR_ARG;
     hipStream_t st = tpg_stream(stream);
-    if (N <= 256) fps_go<64, 4>(xyz, B, N, m, idx, start, skip_origin, st);
-    else if (N <= 512) fps_go<128, 4>(xyz, B, N, m, idx, start, skip_origin, st);
-#if defined(TPG_FPS_1024_BLOCK)
-    else if (N <= 1024) fps_go<TPG_FPS_1024_BLOCK, 1024 / TPG_FPS_1024_BLOCK>(xyz, B, N, m, idx, start, skip_origin, st);
-#else
-    else if (N <= 1024) fps_go<256, 4>(xyz, B, N, m, idx, start, skip_origin, st);
+    // Workgroup shape (tools/tune_fps.py): one wave per SIMD first (4 waves), then up to 16 points per
+    // thread before more waves -- a round is VALU-issue bound on its one CU, and every extra wave
+    // repeats the reduction and lengthens the barrier.  (4096 points: 0.57 us/round with 256 threads,
+    // 0.59 with 512, 0.63 with 1024.)
+#define TPG_FPS_SHAPE(n, block) fps_go<block, (n) / (block)>(xyz, B, N, m, idx, start, skip_origin, st)
+#ifndef TPG_FPS_1024_BLOCK
+#define TPG_FPS_1024_BLOCK 256
 #endif
-    else if (N <= 2048) fps_go<512, 4>(xyz, B, N, m, idx, start, skip_origin, st);
-#if defined(TPG_FPS_4096_BLOCK)
-    else if (N <= 4096) fps_go<TPG_FPS_4096_BLOCK, 4096 / TPG_FPS_4096_BLOCK>(xyz, B, N, m, idx, start, skip_origin, st);
-#else
-    else if (N <= 4096) fps_go<1024, 4>(xyz, B, N, m, idx, start, skip_origin, st);
+#ifndef TPG_FPS_2048_BLOCK
+#define TPG_FPS_2048_BLOCK 256
 #endif
-    else if (N <= 8192) fps_go<1024, 8>(xyz, B, N, m, idx, start, skip_origin, st);
-    else if (N <= 16384) fps_go<1024, 16>(xyz, B, N, m, idx, start, skip_origin, st);
+#ifndef TPG_FPS_4096_BLOCK
+#define TPG_FPS_4096_BLOCK 256
+#endif
+#ifndef TPG_FPS_8192_BLOCK
+#define TPG_FPS_8192_BLOCK 512
+#endif
+    if (N <= 256) TPG_FPS_SHAPE(256, 64);
+    else if (N <= 512) TPG_FPS_SHAPE(512, 128);
+    else if (N <= 1024) TPG_FPS_SHAPE(1024, TPG_FPS_1024_BLOCK);
+    else if (N <= 2048) TPG_FPS_SHAPE(2048, TPG_FPS_2048_BLOCK);
+    else if (N <= 4096) TPG_FPS_SHAPE(4096, TPG_FPS_4096_BLOCK);
+    else if (N <= 8192) TPG_FPS_SHAPE(8192, TPG_FPS_8192_BLOCK);
+    else if (N <= 16384) TPG_FPS_SHAPE(16384, 1024);
     else {
         if (!temp) return TPG_ERR_ARG;
         hipLaunchKernelGGL(fps_big_kernel, dim3(B), dim3(1024), 0, st, xyz, N, m, temp, idx, start, skip_origin);

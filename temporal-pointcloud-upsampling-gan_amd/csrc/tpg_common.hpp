@@ -89,6 +89,17 @@ __device__ __forceinline__ int tpg_wave_max_i32(int v) {
     v = max(v, tpg_dpp_rows<0x143, 0xC>(v));
     return __builtin_amdgcn_readlane(v, 63);
 }
+// same value; the four row maxima are combined on the scalar unit (4 readlanes + 3 s_max
+// instead of two masked row_bcast steps of 3 VALU instructions each)
+__device__ __forceinline__ int tpg_wave_max_i32_rows(int v) {
+    v = max(v, tpg_dpp_full<0xB1>(v));
+    v = max(v, tpg_dpp_full<0x4E>(v));
+    v = max(v, tpg_dpp_full<0x124>(v));
+    v = max(v, tpg_dpp_full<0x128>(v));
+    const int a = __builtin_amdgcn_readlane(v, 0), b = __builtin_amdgcn_readlane(v, 16);
+    const int c = __builtin_amdgcn_readlane(v, 32), d = __builtin_amdgcn_readlane(v, 48);
+    return max(max(a, b), max(c, d));
+}
 __device__ __forceinline__ unsigned tpg_wave_min_u32(unsigned v) {
     v = min(v, (unsigned)tpg_dpp_full<0xB1>((int)v));
     v = min(v, (unsigned)tpg_dpp_full<0x4E>((int)v));

@@ -10,10 +10,11 @@ import sys
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 CSRC = os.path.join(ROOT, "temporal-pointcloud-upsampling-gan_amd", "csrc")
 VDIR = os.path.join(CSRC, "variants")
-VARIANTS = {"default": {}, "b512": {"TPG_FPS_4096_BLOCK": 512, "TPG_FPS_1024_BLOCK": 128},
-            "b256": {"TPG_FPS_4096_BLOCK": 256, "TPG_FPS_1024_BLOCK": 64},
-            "b128": {"TPG_FPS_4096_BLOCK": 128, "TPG_FPS_1024_BLOCK": 64}}
-SHAPES = [(8, 4096, 1024), (24, 4096, 1024), (24, 1024, 256), (8, 1024, 512)]
+VARIANTS = {"default": {},
+            "wide": {"TPG_FPS_1024_BLOCK": 256, "TPG_FPS_2048_BLOCK": 512, "TPG_FPS_4096_BLOCK": 1024, "TPG_FPS_8192_BLOCK": 1024},
+            "mid": {"TPG_FPS_1024_BLOCK": 128, "TPG_FPS_2048_BLOCK": 256, "TPG_FPS_4096_BLOCK": 512, "TPG_FPS_8192_BLOCK": 1024},
+            "narrow": {"TPG_FPS_1024_BLOCK": 64, "TPG_FPS_2048_BLOCK": 128, "TPG_FPS_4096_BLOCK": 256, "TPG_FPS_8192_BLOCK": 512}}
+SHAPES = [(24, 4096, 1024), (24, 1024, 256), (8, 1024, 512), (8, 2048, 512), (8, 8192, 1024), (8, 512, 128)]
 
 
 def build():
