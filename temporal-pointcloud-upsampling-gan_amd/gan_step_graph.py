@@ -35,11 +35,13 @@ Multi-GPU: with `sync.world_size > 1` the step is captured as two graphs (`_phas
 `_phase_apply`) and ONE flat gradient all-reduce over the three networks runs eagerly between
 them (RCCL calls are kept out of capture).
 """
+import contextlib
 import os
 
 import numpy as np
 import torch
 
+from .graph_conv import shadows
 from .gan_step import _frozen, _autocast, _set_dummy_check, _NoSync, get_rotation_matrix, tempo_gan_step
 from .losses import tpugan_sr_loss
 from .set_abstraction import _plan_tensors, attach_plan_inverses, run_index_plan
@@ -267,6 +269,21 @@ class GraphedFluidStep:
         norm iterations, BatchNorm running statistics), and every optimizer step comes in
         `_phase_apply`, after the generator's backward -- which still reads the discriminators'
         parameters -- has finished."""
+        with self._shadows():
+            self._grads_body(update_D)
+
+    def _shadows(self):
+        """Low-precision copies of every parameter, cast with ONE launch (graph_conv.shadows): made
+        once the state sits in its flat buffers, refreshed at the head of every step."""
+        if self.amp is None or not getattr(self, "_state", None):
+            return contextlib.nullcontext()
+        if getattr(self, "_shadow", None) is None:
+            params = [p for m in (self.G, self.Ds, self.Dt) for p in m.parameters()]
+            self._shadow = shadows(self._state, params, self.amp)
+        self._shadow.refresh()
+        return self._shadow
+
+    def _grads_body(self, update_D):
         sr_loss = self._seg_generator(update_D, defer_backward=True)
         k, lab = self._keep, self.lab
         main = torch.cuda.current_stream(self.dev)

@@ -107,6 +107,54 @@ def conv_bn_layer(in_feat, out_feat, act=False, norm="batch", sn=False):
     return nn.Sequential(*layers)
 
 
+# Low-precision shadow copies of parameters.  Under autocast every use of a weight is its own
+# cast launch (~2.5 us of kernel, ~5 us of dependent-launch latency in a hipGraph: ~35 of them in
+# one generator forward).  A step that owns its parameters (gan_step_graph.GraphedFluidStep keeps
+# them in one flat buffer) casts the whole buffer with ONE launch per step and registers the views
+# here; `shadow_cast` then finds them by address.  Nothing is registered outside such a step.
+_SHADOW = {"on": False, "dtype": None, "map": {}}
+
+
+def shadow_cast(t, dtype):
+    """t.to(dtype) -- or, inside a step that registered shadows, the copy it already made."""
+    if _SHADOW["on"] and dtype == _SHADOW["dtype"] and t.dtype != dtype and t.is_contiguous():
+        hit = _SHADOW["map"].get((t.data_ptr(), t.numel()))
+        if hit is not None:
+            return hit.view(t.shape)
+    return t.to(dtype)
+
+
+class shadows:
+    """with shadows(flat_buffers, parameters, dtype): ... -- inside, `shadow_cast(p, dtype)` of a
+    registered parameter (or a contiguous same-size view of it) returns a view of ONE buffer that
+    `refresh()` fills with a single cast launch.  The caller refreshes after every change of the
+    parameters and before their first use."""
+
+    def __init__(self, flats, params, dtype):
+        self.dtype = dtype
+        self.flats = [f for f in flats if f.is_floating_point() and f.dtype != dtype]
+        self.copies = [torch.empty_like(f, dtype=dtype) for f in self.flats]
+        self.map = {}
+        for p in params:
+            for f, c in zip(self.flats, self.copies):
+                off = (p.data_ptr() - f.data_ptr()) // f.element_size()
+                if p.dtype == f.dtype and 0 <= off and off + p.numel() <= f.numel() and p.is_contiguous():
+                    self.map[(p.data_ptr(), p.numel())] = c[off:off + p.numel()]
+
+    def refresh(self):
+        for f, c in zip(self.flats, self.copies):
+            c.copy_(f)
+
+    def __enter__(self):
+        self._saved = dict(_SHADOW)
+        _SHADOW.update(on=True, dtype=self.dtype, map=self.map)
+        return self
+
+    def __exit__(self, *exc):
+        _SHADOW.update(self._saved)
+        return False
+
+
 class _TallLinear(torch.autograd.Function):
     """y = x @ W^T for TALL x (P rows >> C): same forward GEMM as F.linear, but the weight
     gradient dW = gy^T x -- a (Cout x Cin) output with K = P up to 2.6e5 -- is computed as a
@@ -117,13 +165,13 @@ class _TallLinear(torch.autograd.Function):
     @staticmethod
     def forward(ctx, x, w, bias, dtype):
         xd = x.to(dtype)
-        wd = w.to(dtype)
+        wd = shadow_cast(w, dtype)
         ctx.save_for_backward(xd, wd)
         ctx.w_dtype, ctx.x_dtype = w.dtype, x.dtype
         ctx.b_dtype = None if bias is None else bias.dtype
         if bias is None:
             return xd @ wd.t()
-        return torch.addmm(bias.to(dtype), xd, wd.t())            # bias in the GEMM epilogue
+        return torch.addmm(shadow_cast(bias, dtype), xd, wd.t())  # bias in the GEMM epilogue
 
     @staticmethod
     def backward(ctx, gy):
