@@ -348,11 +348,16 @@ __global__ __launch_bounds__(BN_THREADS) void rowbn_apply_kernel(
 // groups of K consecutive rows -> one row (max) + arg-max byte per channel (first maximum).
 // A thread walks whole groups; the walk over (group, k) is one pipeline (U rows per stage,
 // U | K), so the loads of the next group's first rows are in flight while a group is closed.
+// Few long groups (a GroupAll level: 8 clouds x 256 rows) leave that walk a handful of threads
+// with 64 dependent stages each: then a group is cut into L runs of K/L rows, a thread walks runs,
+// writes the run's fp32 maximum and arg-max byte to `part` / `parg`, and rowbn_max_combine_kernel
+// takes the first maximum over the L runs (L == 1: straight to y / arg).
 template <typename TI, typename TO, int U>
 __global__ __launch_bounds__(BN_THREADS) void rowbn_apply_max_kernel(
     const TI *__restrict__ x, long long Gp, int K, int C, const float *__restrict__ mean,
     const float *__restrict__ rstd, const float *__restrict__ gamma, const float *__restrict__ beta,
-    float slope, TO *__restrict__ y, uint8_t *__restrict__ arg) {
+    float slope, TO *__restrict__ y, uint8_t *__restrict__ arg, int L, float *__restrict__ part,
+    uint8_t *__restrict__ parg) {
     constexpr int NE = (sizeof(TI) == 2 || sizeof(TO) == 2) ? 8 : 4;
     const int cpr = C / NE, rpi = BN_THREADS / cpr;
     const int chunk = threadIdx.x % cpr, rsub = threadIdx.x / cpr, col = chunk * NE;
@@ -360,6 +365,12 @@ __global__ __launch_bounds__(BN_THREADS) void rowbn_apply_max_kernel(
     x += (size_t)blockIdx.y * Gp * K * C;
     y += (size_t)blockIdx.y * Gp * C;
     arg += (size_t)blockIdx.y * Gp * C;
+    if (L > 1) {
+        part += (size_t)blockIdx.y * Gp * L * C;
+        parg += (size_t)blockIdx.y * Gp * L * C;
+        Gp *= L;                       // from here on a "group" is a run of K / L rows
+        K /= L;
+    }
     if (mean) { mean += (size_t)blockIdx.y * C; rstd += (size_t)blockIdx.y * C; }
     float a[NE], b[NE], mu[NE];
     ld_consts<NE>(mean, col, 0.0f, mu);
@@ -405,14 +416,23 @@ __global__ __launch_bounds__(BN_THREADS) void rowbn_apply_max_kernel(
             }
         }
         if (kn == 0) {   // group complete
-            Chunk<TO, NE>::store(y + grp * C + col, best);
+            uint8_t *ab = arg;
+            if (L > 1) {                                  // a run: fp32 maximum, k counted in the group
+                Chunk<float, NE>::store(part + grp * C + col, best);
+                const int kb = (int)(grp % L) * K;
+#pragma unroll
+                for (int i = 0; i < NE; ++i) bk[i] += kb;
+                ab = parg;
+            } else {
+                Chunk<TO, NE>::store(y + grp * C + col, best);
+            }
             // NE arg-max bytes (8-byte aligned for NE = 8, 4-byte for NE = 4)
             if constexpr (NE == 8) {
                 const unsigned lo = bk[0] | (bk[1] << 8) | (bk[2] << 16) | ((unsigned)bk[3] << 24);
                 const unsigned hi = bk[4] | (bk[5] << 8) | (bk[6] << 16) | ((unsigned)bk[7] << 24);
-                *reinterpret_cast<uint2 *>(arg + grp * C + col) = make_uint2(lo, hi);
+                *reinterpret_cast<uint2 *>(ab + grp * C + col) = make_uint2(lo, hi);
             } else {
-                *reinterpret_cast<unsigned *>(arg + grp * C + col) =
+                *reinterpret_cast<unsigned *>(ab + grp * C + col) =
                     bk[0] | (bk[1] << 8) | (bk[2] << 16) | ((unsigned)bk[3] << 24);
             }
 #pragma unroll
@@ -424,6 +444,40 @@ __global__ __launch_bounds__(BN_THREADS) void rowbn_apply_max_kernel(
         grp = grpn;
         have = have_n;
     }
+}
+
+// first maximum over the L runs of every group (see rowbn_apply_max_kernel); one thread per
+// (group, chunk of NE channels), grid.y = segment
+template <typename TO, int NE>
+__global__ __launch_bounds__(BN_THREADS) void rowbn_max_combine_kernel(
+    const float *__restrict__ part, const uint8_t *__restrict__ parg, long long Gp, int L, int C,
+    TO *__restrict__ y, uint8_t *__restrict__ arg) {
+    const int cpr = C / NE;
+    const long long t = (long long)blockIdx.x * BN_THREADS + threadIdx.x;
+    if (t >= Gp * cpr) return;
+    const long long grp = t / cpr;
+    const int col = (int)(t % cpr) * NE;
+    part += (size_t)blockIdx.y * Gp * L * C + (size_t)grp * L * C + col;
+    parg += (size_t)blockIdx.y * Gp * L * C + (size_t)grp * L * C + col;
+    y += (size_t)blockIdx.y * Gp * C + grp * C + col;
+    arg += (size_t)blockIdx.y * Gp * C + grp * C + col;
+    float best[NE];
+    int run[NE];
+#pragma unroll
+    for (int i = 0; i < NE; ++i) { best[i] = -INFINITY; run[i] = 0; }
+#pragma unroll 8
+    for (int l = 0; l < L; ++l) {
+        Chunk<float, NE> c;
+        c.load(part + (size_t)l * C);
+        float v[NE];
+        c.unpack(v);
+#pragma unroll
+        for (int i = 0; i < NE; ++i)
+            if (v[i] > best[i]) { best[i] = v[i]; run[i] = l; }        // strict: the first run wins a tie
+    }
+    Chunk<TO, NE>::store(y, best);
+#pragma unroll
+    for (int i = 0; i < NE; ++i) arg[i] = parg[(size_t)run[i] * C + i];
 }
 
 // ------------------------------------------------------------------ backward reductions
@@ -612,12 +666,13 @@ __global__ __launch_bounds__(BN_THREADS) void rowbn_bwd_apply_kernel(
 }
 
 // K > 0: g lives only on each group's arg-max row; a thread walks whole groups so that gy and
-// the arg-max bytes are read once per group; (group, k) walked as one pipeline like the forward
+// the arg-max bytes are read once per group; (group, k) walked as one pipeline like the forward.
+// L > 1: a group is walked as L runs of K/L rows by L threads (few long groups, see the forward).
 template <typename TI, typename TG, int U>
 __global__ __launch_bounds__(BN_THREADS) void rowbn_bwd_apply_max_kernel(
     const TG *__restrict__ gy, const TI *__restrict__ x, const uint8_t *__restrict__ arg, long long Gp, int K,
     int C, const float *__restrict__ mean, const float *__restrict__ rstd, const float *__restrict__ gamma,
-    const float *__restrict__ beta, float slope, const float *__restrict__ c12, TI *__restrict__ dx) {
+    const float *__restrict__ beta, float slope, const float *__restrict__ c12, TI *__restrict__ dx, int L) {
     constexpr int NE = (sizeof(TI) == 2 || sizeof(TG) == 2) ? 8 : 4;
     const int cpr = C / NE, rpi = BN_THREADS / cpr;
     const int chunk = threadIdx.x % cpr, rsub = threadIdx.x / cpr, col = chunk * NE;
@@ -637,6 +692,8 @@ __global__ __launch_bounds__(BN_THREADS) void rowbn_bwd_apply_max_kernel(
     ld_consts<NE>(c12 ? c12 + C : nullptr, col, 0.0f, c2);
 #pragma unroll
     for (int i = 0; i < NE; ++i) a[i] = a[i] * rs[i];
+    Gp *= L;                           // runs of K / L rows; run r belongs to group r / L
+    K /= L;
     const long long gstep = (long long)gridDim.x * rpi;
     long long grp = (long long)blockIdx.x * rpi + rsub;
     int k = 0;
@@ -645,7 +702,8 @@ __global__ __launch_bounds__(BN_THREADS) void rowbn_bwd_apply_max_kernel(
     Chunk<TG, NE> cgy, ngy;
     unsigned ak_lo = 0, ak_hi = 0, nk_lo = 0, nk_hi = 0;     // NE arg-max bytes
     const TI *xc = x + col;
-    auto load_group = [&](long long g_, Chunk<TG, NE> &cg, unsigned &lo, unsigned &hi) {
+    auto load_group = [&](long long r_, Chunk<TG, NE> &cg, unsigned &lo, unsigned &hi) {
+        const long long g_ = r_ / L;
         cg.load(gy + g_ * C + col);
         if constexpr (NE == 8) {
             const uint2 t = *reinterpret_cast<const uint2 *>(arg + g_ * C + col);
@@ -673,6 +731,7 @@ __global__ __launch_bounds__(BN_THREADS) void rowbn_bwd_apply_max_kernel(
         }
         float g[NE];
         cgy.unpack(g);
+        const int kb = (int)(grp % L) * K;                 // this run's first k inside its group
 #pragma unroll
         for (int u = 0; u < U; ++u) {
             float v[NE];
@@ -681,7 +740,7 @@ __global__ __launch_bounds__(BN_THREADS) void rowbn_bwd_apply_max_kernel(
             for (int i = 0; i < NE; ++i) {
                 const int ak = (int)(((i < 4 ? ak_lo : ak_hi) >> (8 * (i & 3))) & 0xffu);
                 float gg = 0.0f;
-                if (ak == k + u) gg = bn_z(v[i], mu[i], a[i], b[i]) > 0.0f ? g[i] : g[i] * slope;
+                if (ak == kb + k + u) gg = bn_z(v[i], mu[i], a[i], b[i]) > 0.0f ? g[i] : g[i] * slope;
                 v[i] = a[i] * (gg - c1[i] - (v[i] - mu[i]) * rs[i] * c2[i]);
             }
             Chunk<TI, NE>::store(dx + (grp * K + k + u) * C + col, v);
@@ -713,6 +772,17 @@ int seg_blocks(int blocks, int nseg) {
     return b < 1 ? 1 : b;
 }
 int group_unroll(int K) { return K % 4 == 0 ? 4 : (K % 2 == 0 ? 2 : 1); }
+// Runs per group for the max-variant walks: 1 unless the launch would have fewer than ~64 K
+// threads at work; then the largest power of two that keeps runs of >= 4 rows (a multiple of
+// the pipeline depth) and, for the forward, the runs' partial results inside the workspace
+// (`room` runs per segment; 0 = no limit).
+int group_runs(long long Gp, int K, int cpr, int nseg, long long room) {
+    int L = 1;
+    while (K % (2 * L) == 0 && (K / (2 * L)) % 4 == 0 && Gp * L * cpr * nseg < 65536 &&
+           (room == 0 || Gp * 2 * L <= room))
+        L *= 2;
+    return L;
+}
 
 }  // namespace
 
@@ -765,13 +835,27 @@ extern "C" int tpg_rowbn_fwd(const void *x, int dtype_in, long long P, int K, in
     const long long rows_out = K > 0 ? P / K : P;
     // several segments share the chip: fewer workgroups per segment
     const int cap_div = nseg > 4 ? 4 : nseg;
-    const dim3 g(K > 0 ? row_blocks(rows_out, rpi_a, 1, TPG_BN_GROUP_CAP / cap_div)
+    // runs' partial maxima live where the statistics' partial sums were (already consumed):
+    // (float + byte) per channel and run, BN_MAX_BLOCKS * 2 floats per channel and segment
+    const int L = K > 0 ? group_runs(rows_out, K, C / ne, nseg, BN_MAX_BLOCKS * 8 / 5) : 1;
+    const dim3 g(K > 0 ? row_blocks(rows_out * L, rpi_a, 1, TPG_BN_GROUP_CAP / cap_div)
                        : row_blocks(P, rpi_a, TPG_BN_APPLY_ROWS, TPG_BN_APPLY_CAP / cap_div), nseg);
     const dim3 blk(BN_THREADS);
-    const int gu = group_unroll(K);
+    const int gu = group_unroll(K / L);
+    float *part = static_cast<float *>(ws) + WS_HEAD;
+    uint8_t *parg = reinterpret_cast<uint8_t *>(part + (size_t)nseg * rows_out * L * C);
 #define TPG_BN_APPLY_MAX(TI, TO, U)                                                                       \
-    hipLaunchKernelGGL((rowbn_apply_max_kernel<TI, TO, U>), g, blk, 0, st, static_cast<const TI *>(x),    \
-                       rows_out, K, C, mean, rstd, gamma, beta, slope, static_cast<TO *>(y), argmax)
+    do {                                                                                                  \
+        hipLaunchKernelGGL((rowbn_apply_max_kernel<TI, TO, U>), g, blk, 0, st, static_cast<const TI *>(x), \
+                           rows_out, K, C, mean, rstd, gamma, beta, slope, static_cast<TO *>(y), argmax, L, part, \
+                           parg);                                                                         \
+        if (L > 1) {                                                                                      \
+            constexpr int NE_ = (sizeof(TI) == 2 || sizeof(TO) == 2) ? 8 : 4;                             \
+            const long long thr = rows_out * (C / NE_);                                                   \
+            hipLaunchKernelGGL((rowbn_max_combine_kernel<TO, NE_>), dim3((unsigned)((thr + BN_THREADS - 1) / BN_THREADS), nseg), \
+                               blk, 0, st, part, parg, rows_out, L, C, static_cast<TO *>(y), argmax);     \
+        }                                                                                                 \
+    } while (0)
 #define TPG_BN_APPLY(TI, TO)                                                                              \
     do {                                                                                                  \
         if (K > 0) {                                                                                      \
@@ -817,7 +901,8 @@ extern "C" int tpg_rowbn_bwd(const void *gy, int dtype_g, const void *x, int dty
     const long long rows_g = K > 0 ? P / K : P;
     const int G = seg_blocks(K > 0 ? row_blocks(rows_g, rpi, TPG_BN_YRED_ROWS, BN_MAX_BLOCKS) : stats_blocks(rows_g, rpi), nseg);
     const int cap_div = nseg > 4 ? 4 : nseg;
-    const int GA = K > 0 ? row_blocks(rows_g, rpi, 1, TPG_BN_GROUP_CAP / cap_div)
+    const int L = K > 0 ? group_runs(rows_g, K, C / ne, nseg, 0) : 1;
+    const int GA = K > 0 ? row_blocks(rows_g * L, rpi, 1, TPG_BN_GROUP_CAP / cap_div)
                          : row_blocks(P, rpi, TPG_BN_APPLY_ROWS, TPG_BN_APPLY_CAP / cap_div);
     // no batch statistics and no affine gradients wanted (pure activation [+max]): dx = a * g,
     // nothing to reduce
@@ -825,10 +910,10 @@ extern "C" int tpg_rowbn_bwd(const void *gy, int dtype_g, const void *x, int dty
     const bool need_reduce = wanted && phase != TPG_BN_PHASE_APPLY;
     const bool do_apply = phase != TPG_BN_PHASE_STATS;
     const float *c12_arg = wanted ? c12 : nullptr;     // absent constants read as zero
-    const int gu = group_unroll(K);
+    const int gu = group_unroll(K / L);
 #define TPG_BN_BWD_APPLY_MAX(TI, TG, U)                                                                     \
     hipLaunchKernelGGL((rowbn_bwd_apply_max_kernel<TI, TG, U>), dim3(GA, nseg), dim3(BN_THREADS), 0, st, gg, xx, argmax, \
-                       rows_g, K, C, mean, rstd, gamma, beta, slope, c12_arg, static_cast<TI *>(dx))
+                       rows_g, K, C, mean, rstd, gamma, beta, slope, c12_arg, static_cast<TI *>(dx), L)
 #define TPG_BN_BWD(TI, TG)                                                                                  \
     do {                                                                                                    \
         const TI *xx = static_cast<const TI *>(x);                                                          \
