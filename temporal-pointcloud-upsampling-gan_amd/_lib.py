@@ -9,7 +9,8 @@ import ctypes as C
 import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "csrc", "libtpgan_hip.so")
+# TPGAN_HIP_LIBRARY: another build of the same library (A/B timing of kernel variants on one box)
+LIB_PATH = os.environ.get("TPGAN_HIP_LIBRARY") or os.path.join(_HERE, "csrc", "libtpgan_hip.so")
 
 _P = C.c_void_p
 _I = C.c_int

@@ -765,9 +765,15 @@ bool bn_shape_ok(int dtype_a, int dtype_b, int C) {
     return C > 0 && C % ne == 0 && C / 4 <= BN_THREADS;   // <= 1024 channels (column-sum layout)
 }
 bool bn_dtype_ok(int d) { return d == TPG_DTYPE_F32 || d == TPG_DTYPE_BF16; }
-// workgroups per segment of a reduction when nseg segments share the launch
+// workgroups per segment of a reduction when nseg segments share the launch.  (Alone, 2-3
+// segments run 17-22 % faster with the full count each -- tools/tune_rowbn.py -- but the step
+// gets slower, 66.4 vs 67.3 steps/s on one box: its three branches share the chip, and a launch
+// that fills every CU twice over stalls the other two.)
+#ifndef TPG_BN_SEG_DIV
+#define TPG_BN_SEG_DIV 4      // most segments a launch's workgroup budget is divided by
+#endif
 int seg_blocks(int blocks, int nseg) {
-    const int d = nseg > 4 ? 4 : nseg;
+    const int d = nseg > TPG_BN_SEG_DIV ? TPG_BN_SEG_DIV : nseg;
     const int b = (blocks + d - 1) / d;
     return b < 1 ? 1 : b;
 }
@@ -834,7 +840,7 @@ extern "C" int tpg_rowbn_fwd(const void *x, int dtype_in, long long P, int K, in
     const int rpi_a = BN_THREADS / (C / ne);
     const long long rows_out = K > 0 ? P / K : P;
     // several segments share the chip: fewer workgroups per segment
-    const int cap_div = nseg > 4 ? 4 : nseg;
+    const int cap_div = nseg > TPG_BN_SEG_DIV ? TPG_BN_SEG_DIV : nseg;
     // runs' partial maxima live where the statistics' partial sums were (already consumed):
     // (float + byte) per channel and run, BN_MAX_BLOCKS * 2 floats per channel and segment
     const int L = K > 0 ? group_runs(rows_out, K, C / ne, nseg, BN_MAX_BLOCKS * 8 / 5) : 1;
@@ -900,7 +906,7 @@ extern "C" int tpg_rowbn_bwd(const void *gy, int dtype_g, const void *x, int dty
     const int rpi = BN_THREADS / (C / ne);
     const long long rows_g = K > 0 ? P / K : P;
     const int G = seg_blocks(K > 0 ? row_blocks(rows_g, rpi, TPG_BN_YRED_ROWS, BN_MAX_BLOCKS) : stats_blocks(rows_g, rpi), nseg);
-    const int cap_div = nseg > 4 ? 4 : nseg;
+    const int cap_div = nseg > TPG_BN_SEG_DIV ? TPG_BN_SEG_DIV : nseg;
     const int L = K > 0 ? group_runs(rows_g, K, C / ne, nseg, 0) : 1;
     const int GA = K > 0 ? row_blocks(rows_g * L, rpi, 1, TPG_BN_GROUP_CAP / cap_div)
                          : row_blocks(P, rpi, TPG_BN_APPLY_ROWS, TPG_BN_APPLY_CAP / cap_div);

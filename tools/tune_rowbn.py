@@ -19,19 +19,24 @@ VDIR = os.path.join(CSRC, "variants")
 
 VARIANTS = {
     "base": {},
-    "acap256": {"TPG_BN_APPLY_CAP": 256},
-    "acap256_r4": {"TPG_BN_APPLY_CAP": 256, "TPG_BN_APPLY_ROWS": 4},
     "mb128": {"TPG_BN_MAX_BLOCKS": 128},
     "mb512": {"TPG_BN_MAX_BLOCKS": 512},
-    "mb512_sr16": {"TPG_BN_MAX_BLOCKS": 512, "TPG_BN_STATS_ROWS": 16},
+    "mb1024": {"TPG_BN_MAX_BLOCKS": 1024},
+    "div1": {"TPG_BN_SEG_DIV": 1},
+    "div2": {"TPG_BN_SEG_DIV": 2},
+    "mb512_div2": {"TPG_BN_MAX_BLOCKS": 512, "TPG_BN_SEG_DIV": 2},
     "sr4": {"TPG_BN_STATS_ROWS": 4},
     "sr16": {"TPG_BN_STATS_ROWS": 16},
-    "u8": {"TPG_BN_UNROLL": 8},
+    "su4": {"TPG_BN_STATS_U": 4},
+    "acap512": {"TPG_BN_APPLY_CAP": 512},
+    "acap1024": {"TPG_BN_APPLY_CAP": 1024},
     "bu4": {"TPG_BN_BWD_U": 4},
     "gcap1k": {"TPG_BN_GROUP_CAP": 1024},
 }
-# (P rows, K, C): shared-MLP tails of the discriminators at cfg2 (B=8): level 1..3 + flow embedding
-SHAPES = [(262144, 0, 64), (262144, 32, 128), (65536, 0, 128), (65536, 32, 256), (16384, 0, 256), (16384, 16, 512)]
+# (P rows of ALL segments, K, C, nseg): the shared-MLP tails of the discriminators at cfg2 (B=8) as the
+# step launches them -- T frames x {fake, real} batches as segments
+SHAPES = [(262144, 0, 64, 1), (524288, 0, 64, 2), (786432, 0, 64, 3), (1572864, 0, 64, 6),
+          (524288, 32, 128, 2), (1572864, 32, 128, 6), (393216, 0, 128, 6), (393216, 32, 256, 6)]
 
 
 def build():
@@ -52,7 +57,7 @@ def run(reps):
     st = torch.cuda.current_stream().cuda_stream
     NSETS = 4
     results = {}
-    for (P, K, Cc) in SHAPES:
+    for (P, K, Cc, nseg) in SHAPES:
         rows = P // K if K else P
         sets = []
         for _ in range(NSETS):
@@ -61,7 +66,7 @@ def run(reps):
                              y=torch.empty(rows, Cc, device=dev, dtype=torch.bfloat16),
                              arg=torch.zeros(rows, Cc, device=dev, dtype=torch.uint8)))
         gamma, beta = torch.rand(Cc, device=dev) + 0.5, torch.randn(Cc, device=dev) * 0.1
-        mean, rstd = torch.empty(Cc, device=dev), torch.empty(Cc, device=dev)
+        mean, rstd = torch.empty(nseg * Cc, device=dev), torch.empty(nseg * Cc, device=dev)
         dg, db = torch.empty(Cc, device=dev), torch.empty(Cc, device=dev)
         eb = 2
         bytes_ = {"fwd_stats": P * Cc * eb, "fwd_apply": P * Cc * eb + rows * Cc * (eb + (1 if K else 0)),
@@ -72,7 +77,7 @@ def run(reps):
             lib = C.CDLL(os.path.join(VDIR, f"rowbn_{tag}.so"))
             lib.tpg_rowbn_workspace_bytes.restype = C.c_size_t
             lib.tpg_rowbn_workspace_bytes.argtypes = [I, I]
-            ws = torch.zeros(lib.tpg_rowbn_workspace_bytes(Cc, 1), dtype=torch.uint8, device=dev)
+            ws = torch.zeros(lib.tpg_rowbn_workspace_bytes(Cc, nseg), dtype=torch.uint8, device=dev)
             lib.tpg_rowbn_fwd.argtypes = [P_, I, L, I, I, F, F, I, P_, P_, P_, P_, P_, P_, F, P_, P_, P_, I, P_, P_, I, I, P_]
             lib.tpg_rowbn_bwd.argtypes = [P_, I, P_, I, P_, P_, I, L, I, I, I, P_, P_, P_, P_, F, P_, P_, P_, P_, I, I, P_]
 
@@ -80,14 +85,14 @@ def run(reps):
                 rc = lib.tpg_rowbn_fwd(s["x"].data_ptr(), 1, P, K, Cc, 1e-5, 0.1, 1, None, None, None, None,
                                        gamma.data_ptr(), beta.data_ptr(), 0.2, mean.data_ptr(), rstd.data_ptr(),
                                        s["y"].data_ptr(), 1, s["arg"].data_ptr() if K else None, ws.data_ptr(),
-                                       1, phase, st)
+                                       nseg, phase, st)
                 assert rc == 0, rc
 
             def bwd(s, phase, st=st):
                 rc = lib.tpg_rowbn_bwd(s["gy"].data_ptr(), 1, s["x"].data_ptr(), 1, s["arg"].data_ptr() if K else None,
                                        s["y"].data_ptr() if K else None, 1, P, K, Cc, 1, mean.data_ptr(),
                                        rstd.data_ptr(), gamma.data_ptr(), beta.data_ptr(), 0.2, dg.data_ptr(),
-                                       db.data_ptr(), s["dx"].data_ptr(), ws.data_ptr(), 1, phase, st)
+                                       db.data_ptr(), s["dx"].data_ptr(), ws.data_ptr(), nseg, phase, st)
                 assert rc == 0, rc
 
             for s in sets:      # valid statistics / arg-max / y everywhere
@@ -112,16 +117,16 @@ def run(reps):
                 e1.record()
                 torch.cuda.synchronize()
                 us = e0.elapsed_time(e1) * 1e3 / reps
-                results[(P, K, Cc, name, tag)] = (us, bytes_[name] / us / 1e3)
+                results[(P, K, Cc, nseg, name, tag)] = (us, bytes_[name] / us / 1e3)
         del sets
         torch.cuda.empty_cache()
-    for (P, K, Cc) in SHAPES:
-        print(f"\n== P={P} K={K} C={Cc} (bf16)   us per launch [GB/s; stats/reduce launches include their finalize]")
+    for (P, K, Cc, nseg) in SHAPES:
+        print(f"\n== P={P} K={K} C={Cc} nseg={nseg} (bf16)   us per launch [GB/s; stats/reduce launches include their finalize]")
         print("%-16s" % "variant" + "".join("%22s" % n for n in ("fwd_stats", "fwd_apply", "bwd_reduce", "bwd_apply")))
         for tag in VARIANTS:
             row = "%-16s" % tag
             for n in ("fwd_stats", "fwd_apply", "bwd_reduce", "bwd_apply"):
-                us, gbps = results[(P, K, Cc, n, tag)]
+                us, gbps = results[(P, K, Cc, nseg, n, tag)]
                 row += "%12.1f [%6.0f]" % (us, gbps)
             print(row)
 
