@@ -44,7 +44,7 @@ import torch
 from .graph_conv import shadows
 from .gan_step import _frozen, _autocast, _set_dummy_check, _NoSync, get_rotation_matrix, tempo_gan_step
 from .losses import tpugan_sr_loss
-from .set_abstraction import _plan_tensors, attach_plan_inverses, run_index_plan
+from .set_abstraction import _plan_tensors, attach_plan_inverses, run_index_plan, sn_discard_prepared
 
 
 def _state_tensors(modules, optims):
@@ -188,6 +188,18 @@ class GraphedFluidStep:
         k["plan_t"], _ = run_index_plan(lambda: Dt.merge_plans([upd_t, k["plan_true_t"]]), self.sides[0])
         return join_fs, join_ft, plan_fs, plan_ft
 
+    def _prepare_sn_in_gap(self):
+        """Called (discriminators frozen) right before the generator step's stream waits for the
+        fake clouds' index plans: the spectral-norm power iterations of the two forwards that follow
+        run in that wait (+2.5 % steps/s).  They must stay on THIS stream: started beside the
+        generator's forward on a side stream the replayed step gets 1.2-1.5 ms slower, and update
+        weights made on a side stream put their autograd node there, on which hipStreamEndCapture
+        segfaults (ROCm 7.2)."""
+        if self.use_plans:
+            sn_discard_prepared()
+            self.Ds.prepare_sn(1)
+            self.Dt.prepare_sn(self.T, 1)
+
     def _join_sides(self, stream=None):
         stream = stream or torch.cuda.current_stream(self.dev)
         for sd in self.sides:
@@ -240,6 +252,9 @@ class GraphedFluidStep:
                                                opt.cutoff / self.fd, 11)
         viol = viol | ~(ml.reshape(()) < 0.1)                      # NaN counts as a violation
         with _frozen(Ds, Dt), _autocast(self.amp, self.dev):
+            # this stream is about to wait ~0.5 ms for the index plans: the power iterations of the
+            # two forwards below (they depend on the weights alone) fill the gap
+            self._prepare_sn_in_gap()
             join_fs()
             fake = Ds(fake_s_in, plan=plan_fs)
             spatial_loss = (0.5 * (fake.float() - lab[2]) ** 2).mean()
@@ -270,7 +285,10 @@ class GraphedFluidStep:
         `_phase_apply`, after the generator's backward -- which still reads the discriminators'
         parameters -- has finished."""
         with self._shadows():
-            self._grads_body(update_D)
+            try:
+                self._grads_body(update_D)
+            finally:
+                sn_discard_prepared()          # (nothing left unless the body raised)
 
     def _shadows(self):
         """Low-precision copies of every parameter, cast with ONE launch (graph_conv.shadows): made
@@ -553,6 +571,7 @@ class GraphedActionStep(GraphedFluidStep):
                 update_D, fake_s_in, pred_lst, lambda: pred_c.detach().index_select(1, self.perm_sd),
                 lambda: [p.detach() for p in pred_lst])
             position_loss, cd, _ = tpugan_sr_loss(0, high[1], pred_c, 0., 0., 0., 0)
+            self._prepare_sn_in_gap()
             join_fs()
             fake = Ds(fake_s_in, plan=plan_fs)
             spatial_loss = (0.5 * (fake.float() - lab[2]) ** 2).mean()

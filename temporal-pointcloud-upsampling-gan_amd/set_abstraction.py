@@ -73,16 +73,50 @@ def build_shared_mlp(mlp_spec: List[int], bn: bool = True, sn: bool = True, act_
 _SN_READY = {}
 
 
+# weights computed AHEAD of a forward (sn_prepare): id(module) -> queue of per-forward lists
+_SN_PREPARED = {}
+
+
+def _sn_compute(todo, training):
+    with torch.autocast(device_type=todo[0][0].weight_orig.device.type, enabled=False):
+        ws = ops.spectral_normalize_many([m for m, _ in todo], [k for _, k in todo], training)
+    return [[w.view(m.weight_orig.shape) for w in lst] for (m, _), lst in zip(todo, ws)]
+
+
+def sn_prepare(modules_and_uses, training):
+    """Compute NOW, on the current stream, the weights a later forward's `sn_prefetch` would compute
+    (same arguments): the power iterations depend on the weights alone, so a caller whose stream is
+    about to wait for something else (an index plan) can run them in that gap instead of at the
+    head of the forward (170 us of one-workgroup-per-module work).  Forwards consume prepared sets
+    in the order they were prepared; the caller keeps that the order of the module calls and calls
+    `sn_discard_prepared` if a prepared forward does not happen."""
+    todo = [(m, k) for m, k in modules_and_uses if hasattr(m, "weight_orig") and k > 0]
+    if todo and rows_first():
+        for (m, _), lst in zip(todo, _sn_compute(todo, training)):
+            _SN_PREPARED.setdefault(id(m), []).append(lst)
+
+
+def sn_discard_prepared():
+    _SN_PREPARED.clear()
+
+
 @contextlib.contextmanager
 def sn_prefetch(modules_and_uses, training):
     """Compute, in ONE kernel launch, every spectrally-normalised weight the enclosed forward
-    will ask for: modules_and_uses = [(module, number_of_calls)], in any order."""
+    will ask for: modules_and_uses = [(module, number_of_calls)], in any order.  Weights prepared
+    ahead for this forward (sn_prepare) are taken instead."""
     todo = [(m, k) for m, k in modules_and_uses if hasattr(m, "weight_orig") and k > 0]
     if todo and rows_first():
-        with torch.autocast(device_type=todo[0][0].weight_orig.device.type, enabled=False):
-            ws = ops.spectral_normalize_many([m for m, _ in todo], [k for _, k in todo], training)
-        for (m, _), lst in zip(todo, ws):
-            _SN_READY[id(m)] = [w.view(m.weight_orig.shape) for w in lst]
+        ahead = [m for m, _ in todo if _SN_PREPARED.get(id(m))]
+        if ahead:
+            assert len(ahead) == len(todo), "spectral-norm weights prepared for some modules of a forward only"
+            for m, k in todo:
+                lst = _SN_PREPARED[id(m)].pop(0)
+                assert len(lst) == k, "prepared spectral-norm weights do not match the forward's calls"
+                _SN_READY[id(m)] = lst
+        else:
+            for (m, _), lst in zip(todo, _sn_compute(todo, training)):
+                _SN_READY[id(m)] = lst
     try:
         yield
     finally:
@@ -758,6 +792,11 @@ class _TempoDis(nn.Module):
         calls += [(m, passes) for m in self.fc_layers.modules() if isinstance(m, nn.Linear)]
         return calls
 
+    def prepare_sn(self, T, passes=1):
+        """Spectral-norm weights of a later forward / forward_passes over T frames, computed now
+        (sn_prepare)."""
+        sn_prepare(self._sn_calls(T, passes), self.training)
+
     def merge_plans(self, plans):
         """Index plans of successive forwards (same shapes) -> the plan of `forward_passes`."""
         n0 = plans[0]["sa"][0][1]._tpg_nsrc
@@ -837,6 +876,10 @@ class FluidTempoDis(_TempoDis):
 
 
 class _SpatialDis(nn.Module):
+    def prepare_sn(self, passes=1):
+        """Spectral-norm weights of a later forward / forward_passes, computed now (sn_prepare)."""
+        sn_prepare(self._sn_calls(passes), self.training)
+
     def _sn_calls(self, passes=1):
         calls = []
         for sa in list(self.coarse_graining_module) + [self.SA_pooling]:

@@ -199,3 +199,25 @@ def test_joint_index_plans_equal_separate_index_plans():
     Ds.eval()
     with torch.no_grad():
         assert torch.equal(Ds(clouds[0], plan=joint[0]), Ds(clouds[0], plan=alone[0]))
+
+
+def test_prepared_spectral_norm_weights_equal_the_forwards_own():
+    """sn_prepare + forward == forward (same power iterations, same outputs, same u / v buffers)."""
+    from tpgan_amd.set_abstraction import FluidSpatialDis, sn_discard_prepared
+    from tpgan_amd.synthetic import fluid_clip
+    torch.manual_seed(5)
+    dev = torch.device("cuda", 0)
+    Da = _no_dropout(FluidSpatialDis()).to(dev).train()
+    Db = copy.deepcopy(Da)
+    _, hi = fluid_clip(4, 2048, 8, 3, seed=1, device=dev)
+    Da.prepare_sn(1)
+    Da.prepare_sn(2)                       # two forwards ahead: a single call, then a fake + real pass
+    ya = [Da(hi[0])] + Da.forward_passes([hi[1], hi[2]])
+    yb = [Db(hi[0])] + Db.forward_passes([hi[1], hi[2]])
+    # (the power iteration's cross-workgroup sums are not bitwise reproducible run to run: two inline
+    # forwards of two copies differ by the same 1e-7 in u / v and 1e-4 in the outputs)
+    for a, b in zip(ya, yb):
+        assert torch.allclose(a, b, rtol=0, atol=1e-3)
+    for (n, a), (_, b) in zip(Da.named_buffers(), Db.named_buffers()):
+        assert torch.allclose(a.float(), b.float(), rtol=1e-5, atol=1e-5), n
+    sn_discard_prepared()
