@@ -221,6 +221,14 @@ def main():
         except Exception as e:   # noqa: BLE001 -- never lose the measurement to a capture problem
             GRAPHED = None
             log(f"hipGraph capture failed ({type(e).__name__}: {e}); running eagerly")
+        if world > 1:
+            # the eager step issues other collectives than the replayed one (one all-reduce per
+            # network instead of one flat one): either every rank replays or none does
+            ok = torch.tensor([1.0 if GRAPHED is not None else 0.0], device=device)
+            torch.distributed.all_reduce(ok, op=torch.distributed.ReduceOp.MIN)
+            if GRAPHED is not None and float(ok.item()) == 0.0:
+                GRAPHED = None
+                log(f"rank {rank}: another rank could not capture; running eagerly like it")
     if EAGER_BODY and GRAPHED is not None:
         mode = "captured step body, launched eagerly"
     log(f"rank {rank}: step mode = {mode}")
