@@ -81,6 +81,9 @@ template <typename TA, typename TB> struct Elems {
 #ifndef TPG_RC_BWD_CAP
 #define TPG_RC_BWD_CAP 4096     // most workgroups of a backward launch
 #endif
+#ifndef TPG_RC_BWD_WAVE_CAP
+#define TPG_RC_BWD_WAVE_CAP 16384   // same, wave-per-row form (4 rows per workgroup and pass)
+#endif
 
 // One output chunk = idx read -> row read(s) -> store: a dependent chain of two global loads.  A
 // thread can carry TPG_RC_FWD_U chains at once (all index reads, then all row reads, then the
@@ -312,6 +315,101 @@ __global__ __launch_bounds__(256) void rowcombine_bwd_kernel(
     }
 }
 
+// The same sums with one WAVE per destination row: the C/NE chunk lanes of a row sit side by side
+// (a coalesced row read per entry) and the 64/(C/NE) lane groups take every G-th entry of the row's
+// list, partial sums folded across the groups at the end.  A ball query keeps the first `nsample`
+// points IN INDEX ORDER, so low-index points sit in hundreds of groups: lists of 8-16 entries on
+// average have 100-500 in the tail (tools/rowcombine_lists.py), and with one thread per row the
+// launch lasted as long as its longest list (142 us for 67 MB); here the longest list is walked
+// G entries at a time.  Needs C/NE to divide 64.  (Walking the rows as a three-stage pipeline -- next
+// rows' list bounds and first entries read while this row's gradient rows are in flight -- changed
+// nothing: the launch is not bound by that chain.)
+template <typename TI, typename TG, int MODE>
+__global__ __launch_bounds__(256) void rowcombine_bwd_wave_kernel(
+    const TG *__restrict__ gout, const int32_t *__restrict__ idx, const int32_t *__restrict__ offs,
+    const int32_t *__restrict__ list, const TI *__restrict__ E, int N, int S, int K, int C, float slope,
+    TI *__restrict__ gU, TI *__restrict__ gE, unsigned rows) {
+    constexpr int NE = Elems<TI, TG>::NE;
+    using In = RowIO<TI, NE>;
+    using Gr = RowIO<TG, NE>;
+    const unsigned cpr = (unsigned)C / NE;          // 1, 2, 4 .. 64
+    const unsigned G = 64u / cpr;                   // entries in flight per step
+    const unsigned lane = threadIdx.x & 63u;
+    const unsigned col = (lane % cpr) * NE;
+    const unsigned grp = lane / cpr;
+    const size_t SK = (size_t)S * K;
+    const unsigned wave = (blockIdx.x * 256u + threadIdx.x) >> 6, nwaves = (gridDim.x * 256u) >> 6;
+    for (unsigned drow = wave; drow < rows; drow += nwaves) {
+        const unsigned b = drow / (unsigned)N;
+        const unsigned n = drow - b * (unsigned)N;
+        const int32_t *of = offs + (size_t)b * (N + 1);
+        const int32_t *ls = list + (size_t)b * SK;
+        const TG *go = gout + (size_t)b * SK * C + col;
+        float acc[NE], accE[NE], en[NE];
+#pragma unroll
+        for (int i = 0; i < NE; ++i) { acc[i] = 0.0f; accE[i] = 0.0f; }
+        if (MODE == MODE_EDGE) In::load(E + (size_t)drow * C + col, en);
+        const int p1 = of[n + 1];
+        int p = of[n] + (int)grp;
+        // two entries per lane group in flight
+        for (; p + (int)G < p1; p += 2 * (int)G) {
+            const int e0 = ls[p], e1 = ls[p + G];
+            float g0[NE], g1[NE];
+            Gr::load(go + (size_t)e0 * C, g0);
+            Gr::load(go + (size_t)e1 * C, g1);
+            if (MODE == MODE_EDGE) {
+                float s0[NE], s1[NE];
+                In::load(E + ((size_t)b * N + (unsigned)e0 / (unsigned)K) * C + col, s0);
+                In::load(E + ((size_t)b * N + (unsigned)e1 / (unsigned)K) * C + col, s1);
+#pragma unroll
+                for (int i = 0; i < NE; ++i) {
+                    accE[i] += (en[i] - s0[i] > 0.0f) ? g0[i] : g0[i] * slope;
+                    accE[i] += (en[i] - s1[i] > 0.0f) ? g1[i] : g1[i] * slope;
+                }
+            }
+#pragma unroll
+            for (int i = 0; i < NE; ++i) acc[i] += g0[i] + g1[i];
+        }
+        if (p < p1) {
+            const int e0 = ls[p];
+            float g0[NE];
+            Gr::load(go + (size_t)e0 * C, g0);
+#pragma unroll
+            for (int i = 0; i < NE; ++i) acc[i] += g0[i];
+            if (MODE == MODE_EDGE) {
+                float s0[NE];
+                In::load(E + ((size_t)b * N + (unsigned)e0 / (unsigned)K) * C + col, s0);
+#pragma unroll
+                for (int i = 0; i < NE; ++i) accE[i] += (en[i] - s0[i] > 0.0f) ? g0[i] : g0[i] * slope;
+            }
+        }
+        if (MODE == MODE_EDGE) {
+            // this row as a CENTRE: -sum_k g * lrelu'(E[nbr] - E[n])   (S == N)
+            for (int k = (int)grp; k < K; k += (int)G) {
+                const size_t e = (size_t)n * K + k;
+                const int nb = tpg_clamp_idx(idx[(size_t)b * SK + e], N);
+                float g0[NE], eb[NE];
+                Gr::load(go + e * C, g0);
+                In::load(E + ((size_t)b * N + nb) * C + col, eb);
+#pragma unroll
+                for (int i = 0; i < NE; ++i) accE[i] -= (eb[i] - en[i] > 0.0f) ? g0[i] : g0[i] * slope;
+            }
+        }
+        // fold the lane groups: lanes with the same chunk are cpr apart
+        for (unsigned off = cpr; off < 64u; off <<= 1) {
+#pragma unroll
+            for (int i = 0; i < NE; ++i) {
+                acc[i] += __shfl_xor(acc[i], (int)off, 64);
+                if (MODE == MODE_EDGE) accE[i] += __shfl_xor(accE[i], (int)off, 64);
+            }
+        }
+        if (grp == 0) {
+            if (MODE == MODE_EDGE) In::store(gE + (size_t)drow * C + col, accE);
+            In::store(gU + (size_t)drow * C + col, acc);
+        }
+    }
+}
+
 // gQ[b,s,:] = -sum_k gout[b,s,k,:]
 template <typename TI, typename TG>
 __global__ __launch_bounds__(256) void rowsum_neg_kernel(const TG *__restrict__ gout, int K, int C,
@@ -388,10 +486,25 @@ int bwd_go(const void *gout, const int32_t *idx, const int32_t *offs, const int3
     const TG *go = static_cast<const TG *>(gout);
     const TI *e = static_cast<const TI *>(E);
     TI *gu = static_cast<TI *>(gU), *gq = static_cast<TI *>(gQE);
+    const unsigned cpr = (unsigned)(C / NE);
+#ifndef TPG_RC_BWD_THREAD_PER_ROW
+    const bool by_wave = cpr <= 32 && (64u % cpr) == 0;     // a wave per row needs >= 2 lane groups
+#else
+    const bool by_wave = false;
+#endif
+    const unsigned rows = (unsigned)((unsigned long long)B * N);
+    const unsigned wgs = (rows + 3u) / 4u;                       // 4 waves = 4 rows per workgroup and pass
+    const dim3 gw(wgs > TPG_RC_BWD_WAVE_CAP ? TPG_RC_BWD_WAVE_CAP : wgs);
     if (mode == MODE_EDGE) {
-        hipLaunchKernelGGL((rowcombine_bwd_kernel<TI, TG, MODE_EDGE>), g, blk, 0, st, go, idx, offs, list, e, N, S, K, C, slope, gu, gq, total);
+        if (by_wave)
+            hipLaunchKernelGGL((rowcombine_bwd_wave_kernel<TI, TG, MODE_EDGE>), gw, blk, 0, st, go, idx, offs, list, e, N, S, K, C, slope, gu, gq, rows);
+        else
+            hipLaunchKernelGGL((rowcombine_bwd_kernel<TI, TG, MODE_EDGE>), g, blk, 0, st, go, idx, offs, list, e, N, S, K, C, slope, gu, gq, total);
     } else {
-        hipLaunchKernelGGL((rowcombine_bwd_kernel<TI, TG, MODE_GATHER>), g, blk, 0, st, go, idx, offs, list, e, N, S, K, C, slope, gu, gq, total);
+        if (by_wave)
+            hipLaunchKernelGGL((rowcombine_bwd_wave_kernel<TI, TG, MODE_GATHER>), gw, blk, 0, st, go, idx, offs, list, e, N, S, K, C, slope, gu, gq, rows);
+        else
+            hipLaunchKernelGGL((rowcombine_bwd_kernel<TI, TG, MODE_GATHER>), g, blk, 0, st, go, idx, offs, list, e, N, S, K, C, slope, gu, gq, total);
         if (mode == MODE_SUB) {
             const unsigned totq = (unsigned)totq64;
             hipLaunchKernelGGL((rowsum_neg_kernel<TI, TG>), dim3(grid_for(totq)), blk, 0, st, go, K, C, gq, totq);

@@ -269,6 +269,7 @@ def test_rowcombine_fwd_exact_bwd_close(hip, mode, B, N, S, K, C, din, dout):
     Q = rng.standard_normal((B, S, C)).astype(np.float32)
     idx = rng.integers(0, N, (B, S, K)).astype(np.int32)
     idx[0, 0, :] = 3                      # one heavily repeated destination
+    idx[B - 1, :, 0] = 5                  # a hub: one source row in EVERY group (a list of >= S entries)
     if din == "bf16":
         U, Q = _bf16_round(U), _bf16_round(Q)
     Ud, Qd = dev(U).to(tdt[din]), dev(Q).to(tdt[din])
