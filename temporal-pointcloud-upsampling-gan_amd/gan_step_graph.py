@@ -42,7 +42,7 @@ import numpy as np
 import torch
 
 from .graph_conv import shadows
-from .gan_step import _frozen, _autocast, _set_dummy_check, _NoSync, get_rotation_matrix, tempo_gan_step
+from .gan_step import _frozen, _autocast, _set_dummy_check, _NoSync, tempo_gan_step
 from .losses import tpugan_sr_loss
 from .set_abstraction import _plan_tensors, attach_plan_inverses, run_index_plan, sn_discard_prepared
 
@@ -92,6 +92,18 @@ def _flatten_state(modules, optims):
                     t.set_(view)
             flats.append(flat)
     return flats
+
+
+def _rotation_matrix_np():
+    """gan_step.get_rotation_matrix (same three np.random draws, same Rz*Ry*Rx in fp32) without its
+    five small torch ops: the host's share of a step is GPU idle time (tools/step_gap.py), and a
+    rotating step draws 6 or 16 of these."""
+    a = np.random.uniform(size=3) * 2 * np.pi
+    c, s = np.cos(a), np.sin(a)
+    Rx = np.array([[1., 0, 0], [0, c[0], -s[0]], [0, s[0], c[0]]], dtype=np.float32)
+    Ry = np.array([[c[1], 0, s[1]], [0, 1, 0], [-s[1], 0, c[1]]], dtype=np.float32)
+    Rz = np.array([[c[2], -s[2], 0], [s[2], c[2], 0], [0, 0, 1]], dtype=np.float32)
+    return Rz @ (Ry @ Rx)
 
 
 class GraphedFluidStep:
@@ -448,20 +460,21 @@ class GraphedFluidStep:
         lab_s, lab_t = np.random.uniform(0.8, 1.2), np.random.uniform(0.8, 1.2)
         n_pred = self.perm_c.numel()
         perms = [torch.randperm(n_pred) for _ in range(self.T)]
-        eye = torch.eye(3)
+        eye = np.eye(3, dtype=np.float32)
         rft, rtt = [eye] * self.T, [eye] * self.T
         rfs, rts = [eye] * self.B, [eye] * self.B
         if update_D:
             if np.random.uniform() > 0.7:
-                rft = [get_rotation_matrix() for _ in range(self.T)]
-                rtt = [get_rotation_matrix() for _ in range(self.T)]
+                rft = [_rotation_matrix_np() for _ in range(self.T)]
+                rtt = [_rotation_matrix_np() for _ in range(self.T)]
             if np.random.uniform() > 0.7:
-                rts = [get_rotation_matrix() for _ in range(self.B)]
-                rfs = [get_rotation_matrix() for _ in range(self.B)]
+                rts = [_rotation_matrix_np() for _ in range(self.B)]
+                rfs = [_rotation_matrix_np() for _ in range(self.B)]
         # (the previous step ended with a host sync, so the staging buffers are free to rewrite)
-        self._host_f[:4] = torch.tensor([valid, invalid, lab_s, lab_t], dtype=torch.float32)
-        self._host_f[4:] = torch.stack(rft + rtt + rfs + rts).reshape(-1)
-        self._host_i.copy_(torch.cat(perms))
+        host_f = self._host_f.numpy()                  # the pinned buffer itself
+        host_f[:4] = (valid, invalid, lab_s, lab_t)
+        host_f[4:] = np.stack(rft + rtt + rfs + rts).reshape(-1)
+        torch.cat(perms, out=self._host_i)
 
     def __call__(self, lowres_pos_lst, highres_pos_lst, n_iter, freeze_D=False):
         """Same contract as the eager step function (without velocities); returns its loss dict."""
