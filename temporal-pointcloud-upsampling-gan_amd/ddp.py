@@ -74,6 +74,12 @@ class GradSync:
             off += n
         torch._foreach_copy_(grads, views)          # one multi-tensor launch, not one copy per gradient
 
+    def sum_flat(self, flat):
+        """Sum one already packed buffer over the ranks, in place (the graph-replayed step packs,
+        averages and unpacks inside its graphs: gan_step_graph._capture)."""
+        if self.world_size > 1:
+            dist.all_reduce(flat, op=dist.ReduceOp.SUM, group=self.group)
+
     def broadcast_state(self, *modules, src=0):
         """Make parameters AND buffers (BN stats, spectral-norm u/v) identical at start."""
         if self.world_size == 1:

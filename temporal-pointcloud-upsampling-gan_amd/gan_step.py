@@ -69,6 +69,9 @@ class _NoSync:
     def average_tensors(self, grads):
         pass
 
+    def sum_flat(self, flat):
+        pass
+
 
 @contextlib.contextmanager
 def _frozen(*modules):

@@ -420,9 +420,27 @@ class GraphedFluidStep:
         self._graphs = {}
         for update_D in (True, False):
             graphs, pool = [], None
-            if self.segmented:      # multi-GPU: the gradient all-reduce runs eagerly between two graphs
-                segs = [("grads", lambda u=update_D: self._phase_grads(u), self._reduced(update_D)),
-                        ("apply", lambda u=update_D: self._phase_apply(u), None)]
+            if self.segmented:
+                # multi-GPU: the gradient all-reduce runs eagerly between two graphs.  The first graph ends
+                # by packing every gradient it produced into ONE flat buffer, the second starts by
+                # averaging and unpacking it, so all the host does in between is the collective itself.
+                bucket = {}
+
+                def grads_and_pack(u=update_D, bucket=bucket):
+                    self._phase_grads(u)
+                    # (the gradient tensors THIS capture writes: a later capture rebinds p.grad)
+                    bucket["grads"] = [p.grad for m in self._reduced(u) for p in m.parameters() if p.grad is not None]
+                    bucket["flat"] = torch.cat([g.reshape(-1) for g in bucket["grads"]])
+
+                def unpack_and_apply(u=update_D, bucket=bucket):
+                    flat, views, off = bucket["flat"], [], 0
+                    flat.div_(self.sync.world_size)
+                    for g in bucket["grads"]:
+                        views.append(flat[off:off + g.numel()].view_as(g))
+                        off += g.numel()
+                    torch._foreach_copy_(bucket["grads"], views)
+                    self._phase_apply(u)
+                segs = [("grads", grads_and_pack, bucket), ("apply", unpack_and_apply, None)]
             else:
                 segs = [("all", lambda u=update_D: (self._phase_grads(u), self._phase_apply(u)), None)]
             for name, fn, reduce_module in segs:
@@ -441,13 +459,9 @@ class GraphedFluidStep:
                         torch.cuda.current_stream(self.dev).wait_stream(self.branch2)
                         raise
                 pool = g.pool()
-                if reduce_module is not None:
-                    # the gradient tensors THIS graph writes (a later capture rebinds p.grad to its own
-                    # buffers, so the modules' .grad attributes are not a reliable handle on them)
-                    reduce_module = [p.grad for m in reduce_module for p in m.parameters() if p.grad is not None]
-                graphs.append((g, reduce_module))
+                graphs.append((g, None if reduce_module is None else reduce_module["flat"]))
             self._graphs[update_D] = graphs
-            self._keep_alive = getattr(self, "_keep_alive", []) + [dict(self._keep)]
+            self._keep_alive = getattr(self, "_keep_alive", []) + [dict(self._keep), segs]
         torch.cuda.synchronize(self.dev)
 
     # ------------------------------------------------------------------ one training step
@@ -492,10 +506,10 @@ class GraphedFluidStep:
         self._dev_i.copy_(self._host_i, non_blocking=True)
         for d, t in zip(self._snap, self._state):                       # pre-step snapshot (18 MB, one copy
             d.copy_(t)                                                  # per dtype: the state is flat)
-        for g, grads in self._graphs[update_D]:
+        for g, flat in self._graphs[update_D]:
             g.replay()
-            if grads is not None:
-                self.sync.average_tensors(grads)
+            if flat is not None:
+                self.sync.sum_flat(flat)                # the ONE collective of the step's gradients
         # multi-GPU: the decision to leave the graph path must be COLLECTIVE -- the eager step issues
         # other all-reduces than the replay, so every rank falls back as soon as one rank has to
         viol = self.sync.gate_value(self.viol) if self.sync.world_size > 1 else self.viol
