@@ -10,6 +10,8 @@ only exchanges per step are
     that network (G 1.77 MB, D_tempo 2.95 MB, D_spatial 1.23 MB): at these sizes a
     fully-connected xGMI mesh is latency-bound, so one launch per step beats per-tensor
     hooks, and there is no bucket to tune.
+The graph-replayed step (gan_step_graph) folds all of it into ONE all-reduce per step: the three
+networks' gradients and the rank's regime flag in one bucket, packed and unpacked inside its graphs.
 
 Backend "nccl" is RCCL on ROCm; "gloo" is used by the CPU tests.
 """

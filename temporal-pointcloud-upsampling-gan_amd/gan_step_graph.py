@@ -430,7 +430,9 @@ class GraphedFluidStep:
                     self._phase_grads(u)
                     # (the gradient tensors THIS capture writes: a later capture rebinds p.grad)
                     bucket["grads"] = [p.grad for m in self._reduced(u) for p in m.parameters() if p.grad is not None]
-                    bucket["flat"] = torch.cat([g.reshape(-1) for g in bucket["grads"]])
+                    # (+ this rank's regime flag: its sum tells every rank whether ANY rank left the
+                    # static regime -- the step's second collective folded into the first)
+                    bucket["flat"] = torch.cat([g.reshape(-1) for g in bucket["grads"]] + [self.viol.reshape(1)])
 
                 def unpack_and_apply(u=update_D, bucket=bucket):
                     flat, views, off = bucket["flat"], [], 0
@@ -439,6 +441,7 @@ class GraphedFluidStep:
                         views.append(flat[off:off + g.numel()].view_as(g))
                         off += g.numel()
                     torch._foreach_copy_(bucket["grads"], views)
+                    self.viol.copy_(flat[off:off + 1])
                     self._phase_apply(u)
                 segs = [("grads", grads_and_pack, bucket), ("apply", unpack_and_apply, None)]
             else:
@@ -512,7 +515,8 @@ class GraphedFluidStep:
                 self.sync.sum_flat(flat)                # the ONE collective of the step's gradients
         # multi-GPU: the decision to leave the graph path must be COLLECTIVE -- the eager step issues
         # other all-reduces than the replay, so every rank falls back as soon as one rank has to
-        viol = self.sync.gate_value(self.viol) if self.sync.world_size > 1 else self.viol
+        # (the two-graph form has already summed the flag over the ranks, inside its one all-reduce)
+        viol = self.sync.gate_value(self.viol) if (self.sync.world_size > 1 and not self.segmented) else self.viol
         out = torch.cat([self.report, viol.reshape(1)]).cpu().tolist()   # the step's one host sync
         if out[6] != 0.0:
             # not the static regime: put everything back and take the general path with the same draws

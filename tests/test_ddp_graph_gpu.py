@@ -55,6 +55,24 @@ def _worker(rank, world, port):
     for n_iter, (low, high) in zip((12, 13, 14), (clips[0], clips[1], clips[0])):
         out = step(low, high, n_iter)
         assert all(np.isfinite(v) for v in out.values()), out
+    # ONE rank leaves the static regime: its flag travels inside the gradient all-reduce, and EVERY rank
+    # must restore its snapshot and take the eager step (which issues other collectives than the replay)
+    eager_calls = []
+    inner = step._eager
+    step._eager = lambda *a, **k: (eager_calls.append(1), inner(*a, **k))[1]
+    (g1, flat), second = step._graphs[True]
+
+    class FlagAfter:                                    # this rank's flag raised as if the replay had raised it
+        def replay(self):
+            g1.replay()
+            if rank == 1:
+                flat[-1:].fill_(1.0)
+    step._graphs[True] = [(FlagAfter(), flat), second]
+    out = step(*clips[1], 16)
+    assert len(eager_calls) == 1 and all(np.isfinite(v) for v in out.values()), (eager_calls, out)
+    step._graphs[True] = [(g1, flat), second]
+    out = step(*clips[0], 18)                           # and back on the graph path
+    assert len(eager_calls) == 1
     # data-parallel invariant: identical parameters on every rank after averaged updates
     flat = torch.cat([p.detach().reshape(-1) for m in (G, Dt, Ds) for p in m.parameters()])
     gathered = [torch.zeros_like(flat) for _ in range(world)]
