@@ -21,7 +21,7 @@ KERNELS = {  # bench op name -> substring of the kernel symbol
     "rowbn_fwd_apply": "rowbn_apply_kernel",
     "rowbn_fwd_apply_max": "rowbn_apply_max_kernel",
     "rowcombine_fwd": "rowcombine_fwd_kernel",
-    "rowcombine_bwd": "rowcombine_bwd_kernel",
+    "rowcombine_bwd": "rowcombine_bwd_",             # thread- and wave-per-row forms
     "ball_query": "ball_query_kernel",
     "fps": "fps_kernel",
 }
