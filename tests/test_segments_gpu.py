@@ -8,7 +8,7 @@ import torch
 pytestmark = pytest.mark.gpu
 
 
-@pytest.mark.parametrize("K", [0, 16])
+@pytest.mark.parametrize("K", [0, 16, 256])          # 256: few long groups, walked as runs
 @pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
 def test_row_bn_act_segments_equal_separate_calls(K, dtype):
     import tpgan_amd.ops as ops
