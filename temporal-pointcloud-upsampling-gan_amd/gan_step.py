@@ -177,8 +177,12 @@ def tempo_gan_step(sr_net, spatial_dis, tempo_dis, lowres_pos_lst, lowres_vel_ls
         if use_vel:
             fake_adv, true_adv = pred_adv_lst, gt_adv_lst
         if np.random.uniform() > 0.7:
-            if use_vel:                 # positions and advection features of a frame turn together
-                fakes, fake_adv = rotate_lst(fakes, fake_adv)
+            if use_vel:
+                # Reference quirk kept (train_step_final.py:178): the rotated fake POSITIONS are bound
+                # to a name nobody reads (`pred_pos_lst_detach`), so the temporal discriminator sees
+                # un-rotated fake positions with rotated advection features; the real clouds turn
+                # with their features (:179).  Same draws, same order.
+                _, fake_adv = rotate_lst(fakes, fake_adv)
                 trues, true_adv = rotate_lst(trues, true_adv)
             else:
                 fakes = rotate_lst(fakes)

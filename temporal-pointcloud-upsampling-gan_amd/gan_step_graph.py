@@ -119,6 +119,11 @@ class GraphedFluidStep:
         if segmented is None and os.environ.get("TPGAN_GRAPH_SEGMENTED"):     # measure the multi-GPU form on one GPU
             segmented = os.environ["TPGAN_GRAPH_SEGMENTED"] != "0"
         self.segmented = (self.sync.world_size > 1) if segmented is None else segmented
+        if self.sync.world_size > 1 and not self.segmented:
+            # the single-graph form has no place for the gradient all-reduce: ranks would silently
+            # train independent models
+            raise ValueError("a multi-rank step must be captured as two graphs (segmented=True): "
+                             "the gradient all-reduce runs between them")
         dev = lowres_pos_lst[0].device
         self.dev, self.T, self.B = dev, len(highres_pos_lst), lowres_pos_lst[0].shape[0]
         self.low = [torch.empty_like(x) for x in lowres_pos_lst]
@@ -322,16 +327,9 @@ class GraphedFluidStep:
             self.branch.wait_stream(self.sides[1])      # the spatial update's clouds and index plan
             self.branch2.wait_stream(main)
             self.branch2.wait_stream(self.sides[0])     # the temporal update's
-            with torch.cuda.stream(self.branch):
-                for t in [k["fake_s"], k["true_s"], lab] + _plan_tensors(k["plan_s"]):
-                    t.record_stream(self.branch)
-                with _autocast(self.amp, self.dev):
-                    fake, true = self.Ds.forward_passes([k["fake_s"], k["true_s"]], plan=k["plan_s"])
-                loss_s = (0.5 * ((true.float() - lab[0]) ** 2 + (fake.float() - lab[1]) ** 2)).mean()
-                self.os.zero_grad(set_to_none=True)
-                loss_s.backward()
-                k["spatial_dis_loss"] = loss_s.detach()
-                k["spatial_dis_loss"].record_stream(main)
+            # issue order = the eager step's (and the reference's, train_step_final.py:171-214): the
+            # temporal update first.  The streams decide what runs where; the ISSUE order decides
+            # which Philox offsets the heads' dropout draws get inside a captured graph.
             with torch.cuda.stream(self.branch2):
                 for t in k["fakes"] + k["trues"] + [lab] + _plan_tensors(k["plan_t"]):
                     t.record_stream(self.branch2)
@@ -342,6 +340,16 @@ class GraphedFluidStep:
                 loss_t.backward()
                 k["tempo_dis_loss"] = loss_t.detach()
                 k["tempo_dis_loss"].record_stream(main)
+            with torch.cuda.stream(self.branch):
+                for t in [k["fake_s"], k["true_s"], lab] + _plan_tensors(k["plan_s"]):
+                    t.record_stream(self.branch)
+                with _autocast(self.amp, self.dev):
+                    fake, true = self.Ds.forward_passes([k["fake_s"], k["true_s"]], plan=k["plan_s"])
+                loss_s = (0.5 * ((true.float() - lab[0]) ** 2 + (fake.float() - lab[1]) ** 2)).mean()
+                self.os.zero_grad(set_to_none=True)
+                loss_s.backward()
+                k["spatial_dis_loss"] = loss_s.detach()
+                k["spatial_dis_loss"].record_stream(main)
         else:
             k["tempo_dis_loss"] = torch.zeros((), device=self.dev)
             k["spatial_dis_loss"] = torch.zeros((), device=self.dev)
@@ -493,8 +501,11 @@ class GraphedFluidStep:
         host_f[4:] = np.stack(rft + rtt + rfs + rts).reshape(-1)
         torch.cat(perms, out=self._host_i)
 
-    def __call__(self, lowres_pos_lst, highres_pos_lst, n_iter, freeze_D=False):
-        """Same contract as the eager step function (without velocities); returns its loss dict."""
+    def __call__(self, lowres_pos_lst, highres_pos_lst, n_iter, freeze_D=False, launch_eagerly=False):
+        """Same contract as the eager step function (without velocities); returns its loss dict.
+        launch_eagerly: run the body the graphs were captured from kernel by kernel instead of
+        replaying them -- same streams, same host draws, same state handling; what a replay is
+        compared with in tests/test_graph_gpu.py."""
         update_D = n_iter % 2 == 0 and not freeze_D
         same_shapes = (len(lowres_pos_lst) == len(self.low) and len(highres_pos_lst) == len(self.high)
                        and all(a.shape == b.shape for a, b in zip(lowres_pos_lst, self.low))
@@ -509,14 +520,17 @@ class GraphedFluidStep:
         self._dev_i.copy_(self._host_i, non_blocking=True)
         for d, t in zip(self._snap, self._state):                       # pre-step snapshot (18 MB, one copy
             d.copy_(t)                                                  # per dtype: the state is flat)
-        for g, flat in self._graphs[update_D]:
-            g.replay()
-            if flat is not None:
-                self.sync.sum_flat(flat)                # the ONE collective of the step's gradients
+        if launch_eagerly:
+            self._run_eager(update_D)
+        else:
+            for g, flat in self._graphs[update_D]:
+                g.replay()
+                if flat is not None:
+                    self.sync.sum_flat(flat)            # the ONE collective of the step's gradients
         # multi-GPU: the decision to leave the graph path must be COLLECTIVE -- the eager step issues
-        # other all-reduces than the replay, so every rank falls back as soon as one rank has to
-        # (the two-graph form has already summed the flag over the ranks, inside its one all-reduce)
-        viol = self.sync.gate_value(self.viol) if (self.sync.world_size > 1 and not self.segmented) else self.viol
+        # other all-reduces than the replay -- and it is: the two-graph form has summed the flag over
+        # the ranks inside its one all-reduce
+        viol = self.viol
         out = torch.cat([self.report, viol.reshape(1)]).cpu().tolist()   # the step's one host sync
         if out[6] != 0.0:
             # not the static regime: put everything back and take the general path with the same draws

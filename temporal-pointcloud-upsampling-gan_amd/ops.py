@@ -262,7 +262,9 @@ class HipBackend:
 
     def rowcombine_bwd(self, gout, idx, E, mode, N, slope, in_dtype, inverse=None):
         B, S, K, Cc = gout.shape
-        offs, lst = inverse if inverse is not None else self.invert_index(idx, N)
+        if inverse is None:
+            inverse = _sorted_inverse(idx, N) if _DETERMINISTIC[0] else self.invert_index(idx, N)
+        offs, lst = inverse
         gU = torch.empty((B, N, Cc), dtype=in_dtype, device=gout.device)
         gQE = torch.empty((B, S, Cc), dtype=in_dtype, device=gout.device) if mode != 0 else None
         nbytes = (gout.element_size() * B * S * K * Cc * (2 if mode == 1 else 1) + 8 * B * S * K
@@ -734,6 +736,34 @@ def row_combine(U, QE, idx, mode, slope=0.2, out_dtype=None):
     return _RowCombine.apply(U, QE, idx, mode, float(slope), out_dtype, inverse)
 
 
+_DETERMINISTIC = [False]
+
+
+def set_deterministic(flag):
+    """Debugging aid: build inverted indices with every destination's list in ascending entry order
+    (a stable sort), so that the row gather's backward sums in a fixed order and a training step
+    is bitwise reproducible wherever no float atomic with >= 3 colliding addends is involved (both
+    discriminator updates).  The shipped kernel (tpg_invert_index) fills the lists through LDS
+    atomics: same lists, order inside a list not fixed, sums differ at rounding level from run to
+    run.  tests/test_graph_gpu.py uses this to compare a replayed step with its own body launched
+    kernel by kernel BIT FOR BIT -- a missing dependency edge in the captured graph cannot hide
+    behind "rounding".  Returns the previous setting."""
+    prev, _DETERMINISTIC[0] = _DETERMINISTIC[0], bool(flag)
+    return prev
+
+
+def _sorted_inverse(idx, N):
+    """(offs (B,N+1), list (B,SK)) int32 like tpg_invert_index, lists in ascending entry order."""
+    B = idx.shape[0]
+    flat = idx.reshape(B, -1).clamp(0, N - 1).long()
+    lst = torch.argsort(flat, dim=1, stable=True).to(torch.int32)
+    cnt = torch.zeros((B, N), dtype=torch.int32, device=idx.device)
+    cnt.scatter_add_(1, flat, torch.ones_like(flat, dtype=torch.int32))
+    offs = torch.zeros((B, N + 1), dtype=torch.int32, device=idx.device)
+    offs[:, 1:] = torch.cumsum(cnt, 1)
+    return offs, lst.contiguous()
+
+
 def attach_inverse(idx, N):
     """Prepare the inverted index of a neighbour list idx (B,S,K) int32 into N source rows NOW
     (on the current stream) and hang it on the tensor: `row_combine` hands it to its backward,
@@ -742,7 +772,7 @@ def attach_inverse(idx, N):
     _need(idx.dtype == torch.int32 and idx.dim() == 3 and idx.is_contiguous(), "idx must be contiguous (B,S,K) int32")
     be = backend_for(idx)
     if hasattr(be, "invert_index"):
-        offs, lst = be.invert_index(idx, int(N))
+        offs, lst = _sorted_inverse(idx, int(N)) if _DETERMINISTIC[0] else be.invert_index(idx, int(N))
         idx._tpg_inverse = (int(N), offs, lst)
     return idx
 

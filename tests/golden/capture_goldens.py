@@ -243,8 +243,34 @@ def step_fixture(kind):
     save(f"step_{kind}", **out)
 
 
+# ------------------------------------------------------------------- dataset-side sampler
+def capture_sampling():
+    """`sampling.farthest_point_sampling` (sampling.py:50-106, the numba FPS of the data loaders:
+    train_utils.py:126, tempo_dataset.py:78, msr_dataset.py:94,130) run as plain numpy through the
+    numba pass-through shim: indices for three clouds incl. exact duplicates and points at / near
+    the origin (every point is eligible here, unlike pointnet2's FPS)."""
+    import sampling as ref_sampling
+    out = {}
+    _, high = fluid_clip(1, 2048, 8, 1, seed=40)
+    a = n(high[0][0]).astype(np.float32)
+    _, ahigh = action_clip(1, 1024, 16, 1, seed=41)           # last eighth = exact repeats
+    b = n(ahigh[0][0]).astype(np.float32)
+    c = a[:512].copy()
+    c[3] = 0.0                                                 # a point AT the origin
+    c[100] = np.float32(1e-3) * c[100]                         # and one with |x|^2 << 1e-3
+    c[200:204] = c[7]                                          # a run of duplicates
+    for tag, pts, k, start in (("fluid", a, 256, 5), ("dup", b, 128, 0), ("origin", c, 64, 17)):
+        idx, _ = ref_sampling.farthest_point_sampling(pts, k, initial_idx=start)
+        out[f"{tag}/pts"], out[f"{tag}/k"], out[f"{tag}/start"] = pts, np.int64(k), np.int64(start)
+        out[f"{tag}/idx"] = np.asarray(idx, dtype=np.int64)
+        assert len(set(idx.tolist())) > k // 2
+    save("sampling_fps", **out)
+
+
 if __name__ == "__main__":
-    which = sys.argv[1:] or ["gen", "dis", "loss", "steps"]
+    which = sys.argv[1:] or ["gen", "dis", "loss", "steps", "sampling"]
+    if "sampling" in which:
+        capture_sampling()
     if "gen" in which:
         capture_generator()
     if "dis" in which:

@@ -10,6 +10,7 @@ kernels.  Tolerances: index-derived quantities exact; fp32 features 1e-5 on CPU 
 kernels as the reference run) and 2e-4 on the GPU (different GEMM summation order through
 ~20 layers; the op-level 1e-5 bar is enforced in test_ops_gpu.py).
 """
+import contextlib
 import os
 from argparse import Namespace
 
@@ -18,6 +19,12 @@ import pytest
 import torch
 
 GOLD = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
+# GPU bounds of the reference-order route (hipBLASLt / native conv summation order differs from
+# the CPU run the goldens come from; training-mode BatchNorm on untrained nets multiplies absolute
+# differences by up to 1/sqrt(eps) = 316): measured values are printed by the tests
+GPU_TRAIN_TOL = 5e-3
+GPU_GAN_TOL = 5e-3
+GPU_STATE_TOL = 5e-4
 
 
 def load(name):
@@ -58,6 +65,30 @@ def set_mask_head(net, mode, seed):
 
 def _t(a, dev):
     return torch.from_numpy(np.ascontiguousarray(a)).to(dev)
+
+
+@contextlib.contextmanager
+def cpu_dropout():
+    """Dropout masks drawn from torch's CPU generator, whatever device the activations are on.
+
+    The goldens were captured from the reference on the CPU: its `nn.Dropout` draws
+    `empty_like(x).bernoulli_(1 - p)` from the default CPU generator, interleaved with the step's
+    `torch.randperm` draws (also CPU).  A GPU run draws dropout from the device's Philox stream
+    instead, which made every quantity downstream of a head's Dropout incomparable.  With this
+    patch the GPU run consumes the CPU generator exactly like the reference's run did, so ALL
+    losses, BatchNorm statistics and post-step parameters can be compared on the GPU too."""
+    orig = torch.nn.Dropout.forward
+
+    def forward(self, x):
+        if not self.training or self.p == 0.0:
+            return x
+        noise = torch.empty(x.shape, dtype=torch.float32).bernoulli_(1.0 - self.p).div_(1.0 - self.p)
+        return x * noise.to(device=x.device, dtype=x.dtype)
+    torch.nn.Dropout.forward = forward
+    try:
+        yield
+    finally:
+        torch.nn.Dropout.forward = orig
 
 
 # ------------------------------------------------------------------------------ generator
@@ -140,25 +171,10 @@ def run_discriminators(dev, tol, train_tol=None, state_tol=1e-5):
         m = make()
         check_weights(m, g, f"{name}/w")
         m = m.to(dev).train()
-        if dev == "cpu":
-            torch.manual_seed(100 + i)          # same dropout draws as the reference run
+        torch.manual_seed(100 + i)              # same dropout draws as the reference run
+        with cpu_dropout():                     # (CPU generator on either device)
             close(run(m), g[f"{name}/train"], train_tol)
-            check_weights(m, g, f"{name}/w_after", atol=state_tol)   # BN stats + spectral-norm u/v
-        else:
-            # dropout masks differ on the GPU generator, so the head's BatchNorm1d statistics
-            # (downstream of dropout) are not comparable: check the rest of the state, then
-            # take the head's buffers from a CPU replay of the reference's seeded train pass
-            import copy
-            cpu_twin = copy.deepcopy(m).cpu().train()
-            run(m)
-            check_weights(m, g, f"{name}/w_after", atol=2e-4, skip="fc_layers")
-            torch.manual_seed(100 + i)
-            cpu_run = {"fluid_spatial": lambda mm: mm(high[1].cpu()),
-                       "fluid_tempo": lambda mm: mm([h.cpu() for h in high], 0.10),
-                       "action_spatial": lambda mm: mm(ahigh[1].cpu()),
-                       "action_tempo": lambda mm: mm([h.cpu() for h in ahigh], 2.0)}[name]
-            cpu_run(cpu_twin)
-            m.load_state_dict(cpu_twin.state_dict())
+        check_weights(m, g, f"{name}/w_after", atol=state_tol)       # BN stats + spectral-norm u/v
         m.eval()
         close(run(m), g[f"{name}/eval"], tol)
     # 999-padded clouds, seeded np.random replacement of dummy centres
@@ -193,8 +209,19 @@ def test_discriminators_cpu(oracle_cpu):
 
 
 @pytest.mark.gpu
-def test_discriminators_gpu(oracle_cpu):
-    run_discriminators("cuda", 2e-4)
+def test_discriminators_gpu():
+    """Default order through the HIP kernels: eval logits and BN / spectral-norm state at 2e-4,
+    train-mode logits at the CPU twin's 5e-3 (BatchNorm over variance << eps, see above)."""
+    run_discriminators("cuda", 2e-4, train_tol=5e-3, state_tol=2e-4)
+
+
+@pytest.mark.gpu
+def test_discriminators_reference_order_gpu():
+    """Reference order on the GPU: QueryAndGroup / grouping_operation / GroupAll
+    inside the four discriminators, train AND eval logits, state after the train pass."""
+    from tpgan_amd.set_abstraction import reference_order
+    with reference_order():
+        run_discriminators("cuda", 2e-4, train_tol=GPU_TRAIN_TOL, state_tol=2e-4)
 
 
 # --------------------------------------------------------------------------------- losses
@@ -262,27 +289,24 @@ def run_step(kind, dev, tol, gan_tol=None, state_tol=2e-5):
     os_ = torch.optim.SGD(Ds.parameters(), lr=0.05)
     torch.manual_seed(500)
     np.random.seed(500)
-    if kind == "action":
-        losses = tempo_gan_step_no_mask(G, Ds, Dt, low, high, opt, 12, og, ot, os_)
-    else:
-        losses = tempo_gan_step(G, Ds, Dt, low, None, high, None, 1.0, opt, 12, og, ot, os_)
+    # the reference's draws on either device: np.random and torch.randperm are host generators
+    # already; the heads' dropout masks come from the CPU generator through cpu_dropout()
+    with cpu_dropout():
+        if kind == "action":
+            losses = tempo_gan_step_no_mask(G, Ds, Dt, low, high, opt, 12, og, ot, os_)
+        else:
+            losses = tempo_gan_step(G, Ds, Dt, low, None, high, None, 1.0, opt, 12, og, ot, os_)
     want = {k[5:]: float(g[k]) for k in g.files if k.startswith("loss/")}
     assert set(losses) == set(want)
-    if dev == "cpu":
-        for k in want:
-            t = tol if k in ("Chamfer_distance_no_norm", "masking_loss") else gan_tol
-            assert abs(losses[k] - want[k]) <= t * max(1.0, abs(want[k])), (k, losses[k], want[k])
-        # parameters after one SGD step == reference's, i.e. the gradients agree
-        for tag, m in (("G", G), ("Ds", Ds), ("Dt", Dt)):
-            check_weights(m, g, f"w_after/{tag}", atol=state_tol)
-    else:
-        # GPU torch RNG differs (randperm / dropout draws) -> only RNG-free quantities compare
-        for k in ("Chamfer_distance_no_norm", "masking_loss"):
-            if k in want:
-                assert abs(losses[k] - want[k]) <= tol * max(1.0, abs(want[k])), (k, losses[k], want[k])
-        assert all(np.isfinite(v) for v in losses.values())
-        if kind == "fluid_init":
-            assert losses["tempo_G_loss"] == 0.0 and losses["spatial_D_loss"] == 0.0   # gate closed
+    print(kind, dev, {k: (round(losses[k], 6), round(want[k], 6)) for k in want})
+    for k in want:
+        t = tol if k in ("Chamfer_distance_no_norm", "masking_loss") else gan_tol
+        assert abs(losses[k] - want[k]) <= t * max(1.0, abs(want[k])), (k, losses[k], want[k])
+    # parameters after one SGD step == reference's, i.e. the gradients agree
+    for tag, m in (("G", G), ("Ds", Ds), ("Dt", Dt)):
+        check_weights(m, g, f"w_after/{tag}", atol=state_tol)
+    if kind == "fluid_init":
+        assert losses["tempo_G_loss"] == 0.0 and losses["spatial_D_loss"] == 0.0   # gate closed
 
 
 @pytest.mark.parametrize("kind", ["fluid_keep", "fluid_init", "action"])
@@ -358,7 +382,22 @@ def test_both_orders_give_the_same_gradients(oracle_cpu):
 @pytest.mark.gpu
 @pytest.mark.parametrize("kind", ["fluid_keep", "fluid_init", "action"])
 def test_train_step_gpu(kind):
-    run_step(kind, "cuda", 2e-4)
+    """Default MI355X order on the GPU, the reference's draws (cpu_dropout): the position losses
+    are held at 2e-4; the GAN terms and post-step parameters are not comparable number for number
+    in this order (see test_train_step_cpu) and are pinned by the reference-order twin below."""
+    run_step(kind, "cuda", 2e-4, gan_tol=float("inf"), state_tol=float("inf"))
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("kind", ["fluid_keep", "fluid_init", "action"])
+def test_train_step_reference_order_gpu(kind):
+    """The zero-edit integration route on the GPU: reference order of operations (ball query ->
+    grouping_operation -> conv on grouped positions: `QueryAndGroup`, `_Group` autograd Functions
+    over tpg_group_fwd/bwd, what discriminator.py:190,270-273 would call), the reference's host
+    draws, ALL six losses and the parameters after one SGD step against the goldens."""
+    from tpgan_amd.set_abstraction import reference_order
+    with reference_order():
+        run_step(kind, "cuda", 2e-4, gan_tol=GPU_GAN_TOL, state_tol=GPU_STATE_TOL)
 
 
 def test_use_vel_step_runs_on_the_oracle_backend(oracle_cpu):

@@ -10,17 +10,22 @@ pytestmark = pytest.mark.gpu
 OPT = Namespace(use_vel=False, in_node_feats=3, cutoff=0.025, R=0.10, w=0.5)
 
 
-def _build(dev):
+def _build(dev, dropout=True):
     from tpgan_amd.set_abstraction import FluidSpatialDis, FluidTempoDis
     from tpgan_amd.srnet import SRNet
     from tpgan_amd.synthetic import force_all_keep
     torch.manual_seed(3)
     G = force_all_keep(SRNet(3, 128)).to(dev)
     Ds, Dt = FluidSpatialDis().to(dev), FluidTempoDis(3).to(dev)
-    for m in list(Ds.modules()) + list(Dt.modules()):
-        if isinstance(m, torch.nn.Dropout):
-            m.p = 0.0                           # dropout draws differ between eager and replay
+    if not dropout:
+        for m in list(Ds.modules()) + list(Dt.modules()):
+            if isinstance(m, torch.nn.Dropout):
+                m.p = 0.0
     return G, Ds, Dt
+
+
+def _delta(model, init):
+    return torch.cat([(p.detach() - q).reshape(-1) for p, q in zip(model.parameters(), init)])
 
 
 def _optims(G, Ds, Dt, adam=False):
@@ -154,3 +159,125 @@ def test_action_graph_replay_equals_eager():
         lg = stepper(low, high, it)
         assert all(np.isfinite(v) for v in lg.values())
         assert (lg["tempo_D_loss"] > 0) == (it % 2 == 0)
+
+
+def test_replay_is_bitwise_its_own_body_launched_eagerly():
+    """The race detector for the captured graph ("explain the graph-vs-eager gap").
+
+    A replay and the SAME step body launched kernel by kernel run the same kernels with the same
+    arguments on the same streams; the only thing a replay changes is timing -- the captured
+    dependency edges replace stream order.  With the inverted indices built in a fixed order
+    (ops.set_deterministic) nothing in either discriminator's update depends on timing, so the two
+    must agree BIT FOR BIT -- parameters, BatchNorm statistics, spectral-norm vectors -- for several
+    consecutive G+D and G-only steps, dropout active.  A missing edge between a producer on one
+    stream and a consumer on another (the "stale read" DESIGN 4b records for a discarded join
+    structure) shows up here as a non-zero difference; rounding cannot.  The generator's update
+    goes through one float-atomic scatter with colliding addends (Chamfer's target->source
+    direction), so it is held to 1e-6 relative instead."""
+    from tpgan_amd import ops
+    from tpgan_amd.gan_step_graph import GraphedFluidStep
+    from tpgan_amd.synthetic import fluid_clip
+    dev = torch.device("cuda", 0)
+    prev = ops.set_deterministic(True)
+    try:
+        A = _build(dev)
+        Bm = copy.deepcopy(A)
+        oa, ob = _optims(*A), _optims(*Bm)
+        clips = [fluid_clip(4, 1024, 8, 3, seed=s, device=dev) for s in (1, 2)]
+        sa = GraphedFluidStep(A[0], A[1], A[2], oa, OPT, clips[0][0], clips[0][1], 1.0, None, None)
+        sb = GraphedFluidStep(Bm[0], Bm[1], Bm[2], ob, OPT, clips[0][0], clips[0][1], 1.0, None, None)
+        for it, (low, high) in zip((12, 13, 14), (clips[0], clips[1], clips[1])):
+            init = [[p.detach().clone() for p in m.parameters()] for m in A]
+            np.random.seed(100 + it); torch.manual_seed(100 + it)
+            la = sa(low, high, it)
+            np.random.seed(100 + it); torch.manual_seed(100 + it)
+            lb = sb(low, high, it, launch_eagerly=True)
+            if la["masking_loss"] >= 0.1:          # (a large SGD step closed the gate: both fell back)
+                break
+            assert (la["tempo_D_loss"] > 0) == (it % 2 == 0)
+            for name, ma, mb in (("Ds", A[1], Bm[1]), ("Dt", A[2], Bm[2])):
+                for (k, va), vb in zip(ma.state_dict().items(), mb.state_dict().values()):
+                    assert torch.equal(va, vb), (it, name, k, float((va.float() - vb.float()).abs().max()))
+            da, db = _delta(A[0], init[0]), _delta(Bm[0], init[0])
+            rel = float((da - db).norm() / da.norm())
+            print(f"iteration {it}: D updates bitwise equal; generator delta relative L2 difference {rel:.2e}")
+            assert rel <= 1e-6, (it, rel)
+            for k in la:
+                assert abs(la[k] - lb[k]) <= 1e-6 * max(1.0, abs(la[k])), (it, k, la[k], lb[k])
+    finally:
+        ops.set_deterministic(prev)
+
+
+def test_step_sensitivity_explains_the_replay_vs_eager_gap():
+    """Why `test_graph_replay_equals_eager` holds the parameter deltas to 2e-2 and not to 1e-6.
+
+    The replayed body is a re-organisation of the eager step (stacked generator call, fake / real
+    batch and frames as segments of batched GEMMs, joint index plans): algebraically identical,
+    different GEMM shapes, hence different summation orders at the 1e-7 level.  What that does to a
+    step of UNTRAINED networks is measured here without any graph: the eager step run twice from
+    the same state with the same draws, the second time with the input clouds moved by one part in
+    1e7.  The resulting parameter deltas differ by about as much as replay and eager do (printed
+    side by side), i.e. the gap is the step's own conditioning -- BatchNorm over batch variance
+    << eps (a 316x gain on absolute differences), max-pool arg-max and FPS / ball-query decisions
+    on the generator's near-coincident points -- not something the graph adds.  (That the graph
+    adds nothing is shown bit for bit by the test above.)"""
+    from tpgan_amd.gan_step import tempo_gan_step
+    from tpgan_amd.synthetic import fluid_clip
+    dev = torch.device("cuda", 0)
+    A = _build(dev)
+    Bm = copy.deepcopy(A)
+    oa, ob = _optims(*A), _optims(*Bm)
+    low, high = fluid_clip(4, 1024, 8, 3, seed=1, device=dev)
+    init = [[p.detach().clone() for p in m.parameters()] for m in A]
+    np.random.seed(112); torch.manual_seed(112)
+    tempo_gan_step(A[0], A[1], A[2], low, None, high, None, 1.0, OPT, 12, oa[0], oa[1], oa[2])
+    eps = 1e-7
+    low2, high2 = [x * (1 + eps) for x in low], [x * (1 + eps) for x in high]
+    np.random.seed(112); torch.manual_seed(112)
+    tempo_gan_step(Bm[0], Bm[1], Bm[2], low2, None, high2, None, 1.0, OPT, 12, ob[0], ob[1], ob[2])
+    rels = []
+    for ma, mb, m0 in zip(A, Bm, init):
+        da, db = _delta(ma, m0), _delta(mb, m0)
+        rels.append(float((da - db).norm() / da.norm()))
+    print("eager vs eager with inputs scaled by (1 + 1e-7): relative L2 of the parameter deltas (G, Ds, Dt):", rels)
+    # an input change of 1e-7 moves the update by orders of magnitude more than 1e-7 ...
+    assert max(rels) >= 1e-5
+    # ... and stays inside the bound the replay-vs-eager test uses
+    assert max(rels) <= 2e-2
+
+
+def test_bf16_graph_against_fp32_eager_at_bench_size():
+    """The configuration bench.py times (cfg2: B = 8, N_hi = 4096, T = 3, bf16 autocast, hipGraph
+    replay, Adam) against the fp32 eager step from the same state with the same host draws.
+    Stated bounds: the RNG-free position losses within 2e-3 relative (the generator runs its
+    coordinate arithmetic in fp32 either way), the GAN losses within 5e-2 absolute (bf16 has 8
+    mantissa bits: 4e-3 per rounding, through ~12 discriminator layers with training-mode
+    BatchNorm), and -- with plain SGD so that parameter deltas are the gradients -- the
+    per-network delta within 0.35 relative L2 of the fp32 one (printed)."""
+    from tpgan_amd.gan_step import tempo_gan_step
+    from tpgan_amd.gan_step_graph import GraphedFluidStep
+    from tpgan_amd.synthetic import fluid_clip
+    dev = torch.device("cuda", 0)
+    A = _build(dev, dropout=False)
+    Bm = copy.deepcopy(A)
+    oa, ob = _optims(*A), _optims(*Bm)
+    low, high = fluid_clip(8, 4096, 8, 3, seed=1234, device=dev)
+    init = [[p.detach().clone() for p in m.parameters()] for m in A]
+    stepper = GraphedFluidStep(Bm[0], Bm[1], Bm[2], ob, OPT, low, high, 1.0, torch.bfloat16, None)
+    np.random.seed(7); torch.manual_seed(7)
+    le = tempo_gan_step(A[0], A[1], A[2], low, None, high, None, 1.0, OPT, 12, oa[0], oa[1], oa[2])
+    np.random.seed(7); torch.manual_seed(7)
+    lg = stepper(low, high, 12)
+    print("fp32 eager :", le)
+    print("bf16 replay:", lg)
+    assert le["tempo_D_loss"] > 0 and le["masking_loss"] < 0.1 and lg["tempo_D_loss"] > 0
+    for k in ("Chamfer_distance_no_norm", "masking_loss"):
+        assert abs(le[k] - lg[k]) <= 2e-3 * max(1.0, abs(le[k])), (k, le[k], lg[k])
+    for k in ("tempo_G_loss", "tempo_D_loss", "spatial_G_loss", "spatial_D_loss"):
+        assert abs(le[k] - lg[k]) <= 5e-2, (k, le[k], lg[k])
+    for name, ma, mb, m0 in zip(("G", "Ds", "Dt"), A, Bm, init):
+        da, db = _delta(ma, m0), _delta(mb, m0)
+        rel = float((da - db).norm() / da.norm())
+        cos = float(torch.dot(da, db) / (da.norm() * db.norm()))
+        print(f"bf16 replay vs fp32 eager, {name}: relative L2 of the SGD delta {rel:.3f}, cosine {cos:.4f}")
+        assert rel <= 0.35 and cos >= 0.94, (name, rel, cos)

@@ -498,3 +498,15 @@ def test_dataset_fps_matches_oracle(hip, N, m):
     assert np.array_equal(got[:, 0], start)
     # the pointnet2 rule is unchanged
     assert np.array_equal(hip.fps(dev(pts), m).cpu().numpy(), R.fps(pts, m))
+
+
+def test_dataset_fps_matches_the_reference_fixture(hip):
+    """tpg_fps_start_f32 against indices produced by the reference's own sampling.py:50-106
+    (tests/golden/sampling_fps.npz; capture_goldens.py `sampling`)."""
+    import os
+    import tpgan_amd.ops as ops
+    g = np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "sampling_fps.npz"))
+    for tag in ("fluid", "dup", "origin"):
+        pts, k, start = g[f"{tag}/pts"], int(g[f"{tag}/k"]), int(g[f"{tag}/start"])
+        got = ops.farthest_point_sampling(dev(pts), k, initial_idx=start).cpu().numpy()
+        assert np.array_equal(got, g[f"{tag}/idx"]), tag

@@ -241,3 +241,15 @@ def test_dataset_fps_random_start_no_origin_skip(oracle_cpu):
     assert np.array_equal(one.numpy(), got[1])
     d = ops.sample_patch_with_fps(torch.from_numpy(pts[0]), 256, seed_idx=3, initial_idx=0)
     assert d["patch_pos"].shape == (256, 3) and d["ds_pos"].shape == (32, 3) and int(d["patch_idx"][0]) == 3
+
+
+def test_dataset_fps_oracle_matches_the_reference_fixture():
+    """f4 pinned to the reference: tests/golden/sampling_fps.npz holds the indices
+    `/root/reference/sampling.py:50-106` itself returned (capture_goldens.py, numba shim) for
+    three clouds incl. exact duplicates, a point at the origin and a run of repeats."""
+    import os
+    g = np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "sampling_fps.npz"))
+    for tag in ("fluid", "dup", "origin"):
+        pts, k, start = g[f"{tag}/pts"], int(g[f"{tag}/k"]), int(g[f"{tag}/start"])
+        got = R.fps_start(pts[None], k, np.array([start], np.int32), skip_origin=False)[0]
+        assert np.array_equal(got, g[f"{tag}/idx"]), tag
