@@ -243,6 +243,23 @@ def step_fixture(kind):
     save(f"step_{kind}", **out)
 
 
+def capture_discriminators_t8():
+    """cfg4's temporal discriminator: ActionTempoDis(8) over eight frames = 28 FlowEmbedding calls
+    at seven depths (discriminator.py:286-322,325-402), train-mode logits + state, eval logits."""
+    _, ahigh = action_clip(2, 1024, 16, 8, seed=50)
+    out = {"action8": np.stack([n(h) for h in ahigh])}
+    torch.manual_seed(60)
+    m = ref_dis.ActionTempoDis(8)
+    out.update(pack("action_tempo8/w", checksums(m)))
+    m.train()
+    torch.manual_seed(160)
+    out["action_tempo8/train"] = n(m(list(ahigh), 2.0))
+    out.update(pack("action_tempo8/w_after", checksums(m)))
+    m.eval()
+    out["action_tempo8/eval"] = n(m(list(ahigh), 2.0))
+    save("discriminators_t8", **out)
+
+
 # ------------------------------------------------------------------- dataset-side sampler
 def capture_sampling():
     """`sampling.farthest_point_sampling` (sampling.py:50-106, the numba FPS of the data loaders:
@@ -268,9 +285,11 @@ def capture_sampling():
 
 
 if __name__ == "__main__":
-    which = sys.argv[1:] or ["gen", "dis", "loss", "steps", "sampling"]
+    which = sys.argv[1:] or ["gen", "dis", "loss", "steps", "sampling", "dis8"]
     if "sampling" in which:
         capture_sampling()
+    if "dis8" in which:
+        capture_discriminators_t8()
     if "gen" in which:
         capture_generator()
     if "dis" in which:

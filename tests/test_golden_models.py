@@ -224,6 +224,50 @@ def test_discriminators_reference_order_gpu():
         run_discriminators("cuda", 2e-4, train_tol=GPU_TRAIN_TOL, state_tol=2e-4)
 
 
+def run_action_tempo8(dev, tol, train_tol, state_tol):
+    """cfg4's temporal discriminator: eight frames, 28 FlowEmbedding calls at seven depths."""
+    from tpgan_amd import set_abstraction as SA
+    g = load("discriminators_t8")
+    frames = [_t(x, dev) for x in g["action8"]]
+    torch.manual_seed(60)
+    m = SA.ActionTempoDis(8)
+    check_weights(m, g, "action_tempo8/w")
+    m = m.to(dev).train()
+    torch.manual_seed(160)
+    with cpu_dropout():
+        close(m(list(frames), 2.0), g["action_tempo8/train"], train_tol)
+    check_weights(m, g, "action_tempo8/w_after", atol=state_tol)
+    m.eval()
+    close(m(list(frames), 2.0), g["action_tempo8/eval"], tol)
+
+
+def test_action_tempo8_reference_order_cpu(oracle_cpu):
+    from tpgan_amd.set_abstraction import reference_order
+    with reference_order():
+        run_action_tempo8("cpu", 1e-5, 1e-5, 1e-5)
+
+
+def test_action_tempo8_cpu(oracle_cpu):
+    """Default order.  Train-mode logits at 2e-2: the head's BatchNorm1d normalises over the TWO
+    clips of the batch (measured batch variance down to 1.5e-6 < eps, i.e. up to a 1/sqrt(eps) = 316x
+    gain on the 1e-6-level differences of the two algebraically equal orders after seven chained
+    flow-embedding depths); the running statistics of the head's second BatchNorm sit downstream of
+    that and are held at 5e-4; eval logits (they use those running statistics) at 2e-4."""
+    run_action_tempo8("cpu", 2e-4, 2e-2, 5e-4)
+
+
+@pytest.mark.gpu
+def test_action_tempo8_gpu():
+    run_action_tempo8("cuda", 2e-4, 2e-2, 5e-4)
+
+
+@pytest.mark.gpu
+def test_action_tempo8_reference_order_gpu():
+    from tpgan_amd.set_abstraction import reference_order
+    with reference_order():
+        run_action_tempo8("cuda", 2e-4, 2e-2, 5e-4)
+
+
 # --------------------------------------------------------------------------------- losses
 def run_losses(dev, tol):
     from tpgan_amd import losses

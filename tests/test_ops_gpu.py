@@ -23,7 +23,11 @@ def dev(a):
     return torch.from_numpy(np.ascontiguousarray(a)).cuda()
 
 
-def fluid(rng, B, N, scale=0.25):
+def fluid(rng, B, N, scale=None):
+    """Uniform box with the particle density of the synthetic fluid clips (spacing 0.025):
+    half-width 0.25 at N = 4096, growing with N^(1/3) beyond it."""
+    if scale is None:
+        scale = 0.25 * max(1.0, (N / 4096.0) ** (1.0 / 3.0))
     return rng.uniform(-scale, scale, (B, N, 3)).astype(np.float32)
 
 
@@ -31,7 +35,8 @@ def fluid(rng, B, N, scale=0.25):
 @pytest.mark.parametrize("B,P1,P2,D,K", [
     (2, 512, 512, 3, 20), (2, 512, 512, 32, 9), (2, 512, 512, 32, 20), (2, 512, 512, 64, 12),
     (2, 512, 512, 64, 4), (2, 512, 512, 64, 8), (3, 256, 256, 3, 32), (1, 100, 333, 5, 7),
-    (1, 70, 129, 16, 64), (2, 33, 4096, 3, 16), (1, 5, 3, 3, 8), (1, 64, 64, 3, 1)])
+    (1, 70, 129, 16, 64), (2, 33, 4096, 3, 16), (1, 5, 3, 3, 8), (1, 64, 64, 3, 1),
+    (1, 16384, 16384, 3, 16), (1, 2048, 16384, 3, 32)])     # cfg5 cloud size
 def test_knn_bit_exact(hip, B, P1, P2, D, K):
     rng = np.random.default_rng(B * 1000 + P1 + D + K)
     p1 = rng.standard_normal((B, P1, D)).astype(np.float32)
@@ -72,7 +77,8 @@ def test_knn_ragged(hip):
 
 @pytest.mark.parametrize("B,P1,P2,K,r", [
     (2, 512, 4096, 1, 0.0475), (2, 4096, 4096, 16, 0.035), (3, 256, 256, 32, 2.0),
-    (1, 100, 300, 8, 0.01), (1, 64, 64, 64, 0.2)])
+    (1, 100, 300, 8, 0.01), (1, 64, 64, 64, 0.2),
+    (1, 4096, 16384, 1, 0.0475), (1, 16384, 16384, 16, 0.035)])   # cfg5: masking_loss searches (loss.py:256-265)
 def test_frnn_bit_exact(hip, B, P1, P2, K, r):
     import tpgan_amd.ops as ops
     rng = np.random.default_rng(K)
@@ -107,7 +113,8 @@ def test_chamfer_fwd_bit_exact_bwd_close(hip, B, N, M):
 # ------------------------------------------------------------------ FPS
 @pytest.mark.parametrize("B,N,m", [
     (2, 4096, 1024), (3, 1024, 512), (2, 1024, 256), (2, 512, 128), (2, 200, 64), (1, 64, 64),
-    (2, 2048, 512), (1, 5000, 300), (1, 9000, 200), (1, 20000, 64), (1, 10, 25), (4, 1, 3)])
+    (2, 2048, 512), (1, 5000, 300), (1, 9000, 200), (1, 20000, 64), (1, 10, 25), (4, 1, 3),
+    (2, 16384, 4096)])                                       # cfg5 first level
 def test_fps_bit_exact(hip, B, N, m):
     rng = np.random.default_rng(N + m)
     x = fluid(rng, B, N)
@@ -135,7 +142,8 @@ def test_fps_duplicate_points_tie_to_smallest_index(hip):
 @pytest.mark.parametrize("B,N,S,r,ns", [
     (2, 4096, 1024, 0.10, 32), (2, 4096, 1024, 0.15, 32), (2, 1024, 512, 0.30, 32),
     (2, 512, 128, 0.60, 16), (2, 1024, 256, 0.20, 32), (1, 2048, 512, 0.8, 64),
-    (1, 9000, 77, 0.05, 16), (1, 100, 3, 0.001, 8), (3, 70, 70, 0.2, 100)])
+    (1, 9000, 77, 0.05, 16), (1, 100, 3, 0.001, 8), (3, 70, 70, 0.2, 100),
+    (2, 16384, 1024, 0.10, 32), (1, 16384, 4096, 0.05, 32)])    # cfg5 first level
 def test_ball_query_bit_exact(hip, B, N, S, r, ns):
     rng = np.random.default_rng(N + S + ns)
     x = fluid(rng, B, N)
@@ -294,9 +302,13 @@ def test_rowcombine_fwd_exact_bwd_close(hip, mode, B, N, S, K, C, din, dout):
         assert gQ is None
 
 
-def test_invert_index_is_a_grouped_permutation(hip):
+@pytest.mark.parametrize("N,SK", [(1000, 7777), (16384, 4096 * 32), (16352, 5000), (16353, 5000),
+                                  (40928, 70001), (100000, 150000)])
+def test_invert_index_is_a_grouped_permutation(hip, N, SK):
+    """Incl. the cfg5 cloud size (N_hi = 16384: more counters than the default 64 KB of dynamic LDS
+    hold -- the whole cloud in the CU's 160 KB) and clouds walked as several ranges of rows."""
     rng = np.random.default_rng(2)
-    B, N, SK = 3, 1000, 7777
+    B = 3
     idx = rng.integers(0, N, (B, SK)).astype(np.int32)
     idx[1, :] = 5                         # every entry on one destination
     offs, lst = hip.invert_index(dev(idx).view(B, SK, 1), N)
@@ -307,6 +319,29 @@ def test_invert_index_is_a_grouped_permutation(hip):
         assert np.array_equal(np.diff(offs[b]), np.bincount(idx[b], minlength=N))
         dest = np.repeat(np.arange(N), np.diff(offs[b]))
         assert np.array_equal(idx[b][lst[b]], dest)
+    # the fixed-order form used by the bitwise replay test: same buckets, entries ascending
+    import tpgan_amd.ops as ops
+    offs2, lst2 = ops._sorted_inverse(dev(idx).view(B, SK, 1), N)
+    assert np.array_equal(offs2.cpu().numpy(), offs)
+    for b in range(B):
+        l2 = lst2[b].cpu().numpy()
+        assert np.array_equal(idx[b][l2], np.repeat(np.arange(N), np.diff(offs[b])))
+        same_bucket = np.diff(idx[b][l2]) == 0
+        assert (np.diff(l2)[same_bucket] > 0).all()
+
+
+def test_rowcombine_bwd_at_cfg5_cloud_size(hip):
+    """Row gather backward into N = 16384 source rows (cfg5's clouds: 4 x 4096 predictions / the real
+    clouds entering both discriminators' first level): index-sorted ball-query-like lists."""
+    rng = np.random.default_rng(5)
+    B, N, S, K, C = 2, 16384, 4096, 32, 64
+    idx = np.sort(rng.integers(0, N, (B, S, K)), axis=-1).astype(np.int32)
+    idx[:, :, 0] = rng.integers(0, 64, (B, S))          # hubs among the low indices, like a ball query
+    g = _bf16_round(rng.standard_normal((B, S, K, C)).astype(np.float32))
+    gU, gQ = hip.rowcombine_bwd(dev(g).bfloat16(), dev(idx), None, 1, N, 0.2, torch.float32)
+    rU, rQ = R.rowcombine_bwd(g, idx, None, 1, N, 0.2)
+    assert np.abs(gU.cpu().numpy() - rU).max() <= TOL * max(1.0, np.abs(rU).max())
+    assert np.abs(gQ.cpu().numpy() - rQ).max() <= TOL * max(1.0, np.abs(rQ).max())
 
 
 # ------------------------------------------------------------------ fused BN + act (+max) on rows
