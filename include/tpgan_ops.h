@@ -183,6 +183,65 @@ int tpg_rowbn_bwd(const void *gy, int dtype_g, const void *x, int dtype_in, cons
                   const float *rstd, const float *gamma, const float *beta, float slope, float *dgamma,
                   float *dbeta, void *dx, void *ws, int nseg, int phase, void *stream);
 
+/* the reduction half of tpg_rowbn_bwd alone: c12 (nseg,2,C) = (sum gg / P | sum gg*xhat / P) per segment
+ * (gg = gy * lrelu'), dgamma / dbeta as above; dx is not computed. */
+int tpg_rowbn_bwd_sums(const void *gy, int dtype_g, const void *x, int dtype_in, const uint8_t *argmax,
+                       const void *y, int dtype_y, long long P, int K, int C, int training, const float *mean,
+                       const float *rstd, const float *gamma, const float *beta, float slope, float *dgamma,
+                       float *dbeta, float *c12, void *ws, int nseg, void *stream);
+
+/* ---- fused shared-MLP tail layer on MFMA tiles (csrc/mlp_fused.hip) --------------------------
+ * The grouped-feature x MLP-weight contraction of set abstraction / flow embedding
+ * (discriminator.py:63-78,140-148,276-282: conv1x1 -> BatchNorm2d -> LeakyReLU per layer) for one
+ * layer of the tail, on channels-last bf16 rows:
+ *     y = W . lrelu(scale * x + shift)        x (P,Cin) bf16, W (Cout,Cin) f32, y (P,Cout) bf16
+ * scale | shift = the INPUT BatchNorm folded per channel (ss_in (nseg,2,Cin), NULL = identity), applied
+ * together with the LeakyReLU in the MFMA A-operand prologue; bf16 MFMA (v_mfma_f32_16x16x32_bf16),
+ * fp32 accumulation, one rounding of y; the epilogue accumulates the batch statistics of y (of the
+ * ROUNDED values) and a finalize launch writes mean_out / rstd_out (nseg,Cout), updates
+ * running_mean / running_var / num_batches_tracked like nn.BatchNorm (all three may be NULL;
+ * mean_shift as in tpg_rowbn_fwd) and, if ss_out != NULL, the folded constants of the OUTPUT
+ * BatchNorm (gamma_out, beta_out; NULL = 1 / 0) for the next layer's prologue.
+ * nseg segments = nseg calls of the layer on equal consecutive row blocks, each with its own
+ * statistics and (w_per_seg != 0) its own weight W[seg] (successive spectral-norm iterates).
+ * Supported (Cin,Cout): (64,64) (64,128) (128,64) (128,128) (128,256) (256,128) (256,256);
+ * ws: tpg_mlp_workspace_bytes(max(Cin,Cout), nseg) bytes, 16-byte aligned. */
+size_t tpg_mlp_workspace_bytes(int C, int nseg);
+int tpg_mlp_scale_shift(const float *mean, const float *rstd, const float *gamma, const float *beta, int C,
+                        int nseg, float *ss, void *stream);
+int tpg_mlp_fwd(const void *x, long long P, int Cin, int Cout, int nseg, const float *ss_in, float slope_in,
+                const float *W, int w_per_seg, void *y, float eps, float momentum, float *running_mean,
+                float *running_var, long long *num_batches_tracked, const float *mean_shift,
+                const float *gamma_out, const float *beta_out, float *mean_out, float *rstd_out, float *ss_out,
+                void *ws, void *stream);
+
+/* Backward of such a layer, x_in (P,Cin) -> x_out (P,Cout) = W . lrelu(BN_in(x_in)), followed by
+ * BN_out (+ LeakyReLU; + max over groups of K rows on a tail's last layer).  With BN_out's backward
+ * sums known (c12), the gradient of x_out is elementwise in saved tensors,
+ *     dx_out = a*gg + e - f*x_out      (a, bz, e, f per channel: tpg_mlp_consts, cb (nseg,4,Cout))
+ * and is never stored: it is rebuilt in the MFMA operand prologue of both gradient kernels.
+ *   mode 0 DENSE: gg = g_out (P,Cout) bf16, the activated gradient written by the next layer's dgrad
+ *   mode 1 MAX  : g_out (P/K,Cout) bf16 = gradient of the max output, arg = its arg-max bytes
+ * tpg_mlp_dgrad: g_in (P,Cin) bf16 = (dx_out . W) * lrelu'(z_in) and BN_in's backward sums:
+ *   c12_in (nseg,2,Cin), dgamma_in / dbeta_in (Cin, summed over segments, may be NULL).
+ *   ci_in (nseg,4,Cin) = sc | sh | mu | rs of BN_in (tpg_mlp_consts).  ws: tpg_mlp_workspace_bytes.
+ * tpg_mlp_wgrad: dW (nseg,Cout,Cin) f32 = dx_out^T . lrelu(BN_in(x_in)), both operands rebuilt from the
+ *   saved rows, staged in LDS and read transposed (ds_read_b64_tr_b16); per-workgroup fp32 slabs summed
+ *   in fixed order (bitwise reproducible).  ws: tpg_mlp_wgrad_workspace_bytes(P, Cin, Cout, nseg).
+ * tpg_mlp_bn_bwd_apply: dx = a*(g - c1 - xhat*c2) for the tail's first BatchNorm (g already activated). */
+int tpg_mlp_consts(const float *mean, const float *rstd, const float *gamma, const float *beta, const float *c12,
+                   int C, int nseg, float *ci, float *cb, void *stream);
+int tpg_mlp_dgrad(const void *x_out, const void *g_out, const uint8_t *arg, int K, const float *cb_out,
+                  float slope_out, const void *x_in, const float *ci_in, float slope_in, const float *W,
+                  int w_per_seg, long long P, int Cin, int Cout, int nseg, int mode, void *g_in, float *c12_in,
+                  float *dgamma_in, float *dbeta_in, void *ws, void *stream);
+size_t tpg_mlp_wgrad_workspace_bytes(long long P, int Cin, int Cout, int nseg);
+int tpg_mlp_wgrad(const void *x_out, const void *g_out, const uint8_t *arg, int K, const float *cb_out,
+                  float slope_out, const void *x_in, const float *ci_in, float slope_in, long long P, int Cin,
+                  int Cout, int nseg, int mode, float *dW, void *ws, void *stream);
+int tpg_mlp_bn_bwd_apply(const void *g, const void *x, const float *ci, const float *c12, long long P, int C,
+                         int nseg, void *dx, void *stream);
+
 /* ---- fused spectral normalisation of a (R x Cn) conv / linear weight ------------------------
  * torch.nn.utils.spectral_norm's forward pre-hook (n_power_iterations = 1) on every conv and
  * linear of the discriminators (discriminator.py:66-68,246-247,351-359,...) in ONE launch:

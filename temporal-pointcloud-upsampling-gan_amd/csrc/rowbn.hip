@@ -953,3 +953,24 @@ extern "C" int tpg_rowbn_bwd(const void *gy, int dtype_g, const void *x, int dty
     TPG_RETURN_IF_LAUNCH_FAILED();
     return TPG_OK;
 }
+
+// The reduction half of tpg_rowbn_bwd alone, with its per-channel results handed to the caller:
+// c12 (nseg,2,C) = (sum gg / P | sum gg*xhat / P) per segment, dgamma / dbeta (C, may be NULL).  The
+// fused MLP tail (csrc/mlp_fused.hip) folds these into the constants of its data- and weight-gradient
+// prologues instead of materialising dx.
+extern "C" int tpg_rowbn_bwd_sums(const void *gy, int dtype_g, const void *x, int dtype_in, const uint8_t *argmax,
+                                  const void *y, int dtype_y, long long P, int K, int C, int training,
+                                  const float *mean, const float *rstd, const float *gamma, const float *beta,
+                                  float slope, float *dgamma, float *dbeta, float *c12, void *ws, int nseg,
+                                  void *stream) {
+    if (!c12 || nseg < 1) return TPG_ERR_ARG;
+    // (dx is not written in the statistics phase; any non-null pointer passes the argument check)
+    const int rc = tpg_rowbn_bwd(gy, dtype_g, x, dtype_in, argmax, y, dtype_y, P, K, C, training, mean, rstd, gamma,
+                                 beta, slope, dgamma, dbeta, const_cast<void *>(x), ws, nseg, TPG_BN_PHASE_STATS, stream);
+    if (rc) return rc;
+    const float *src = static_cast<const float *>(ws) + WS_HEAD + (size_t)nseg * BN_MAX_BLOCKS * 2 * C;
+    if (hipMemcpyAsync(c12, src, sizeof(float) * (size_t)nseg * 2 * C, hipMemcpyDeviceToDevice, tpg_stream(stream)) !=
+        hipSuccess)
+        return TPG_ERR_LAUNCH;
+    return TPG_OK;
+}

@@ -333,6 +333,131 @@ class HipBackend:
         return dx, dgamma, dbeta
 
 
+    # ---- fused MLP tail layer on MFMA tiles (csrc/mlp_fused.hip) ---------------------------
+    def _mlp_ws(self, x, C_, nseg):
+        key = ("mlp", x.device, torch.cuda.current_stream(x.device).cuda_stream)
+        ws = self._ws.get(key)
+        need = self.lib.tpg_mlp_workspace_bytes(max(C_, 256), max(nseg, 1)) // 4
+        if ws is None or ws.numel() < need:
+            ws = torch.zeros(need, dtype=torch.float32, device=x.device)
+            self._ws[key] = ws
+        return ws
+
+    def mlp_scale_shift(self, mean, rstd, gamma, beta, C_, nseg, like):
+        ss = torch.empty((nseg, 2, C_), dtype=torch.float32, device=like.device)
+        self._call("tpg_mlp_scale_shift", "mlp_scale_shift", 16 * nseg * C_, like, _ptr(mean), _ptr(rstd),
+                   _ptr(gamma), _ptr(beta), C_, nseg, _ptr(ss))
+        return ss
+
+    def mlp_fwd(self, x, ss_in, slope_in, W, nseg, eps, momentum, running_mean, running_var,
+                num_batches_tracked, mean_shift, gamma_out, beta_out):
+        """y = W . lrelu(ss_in[0] * x + ss_in[1]) on bf16 rows + batch statistics of y.
+        -> y (P,Cout) bf16, mean (nseg,Cout), rstd (nseg,Cout), ss_out (nseg,2,Cout)."""
+        P, Cin = x.shape
+        w_per_seg = int(W.dim() == 3 and W.shape[0] == nseg and nseg > 1)
+        Cout = W.shape[-2]
+        y = torch.empty((P, Cout), dtype=torch.bfloat16, device=x.device)
+        mean = torch.empty((nseg, Cout), dtype=torch.float32, device=x.device)
+        rstd = torch.empty((nseg, Cout), dtype=torch.float32, device=x.device)
+        ss_out = torch.empty((nseg, 2, Cout), dtype=torch.float32, device=x.device)
+        ws = self._mlp_ws(x, max(Cin, Cout), nseg)
+        self._call("tpg_mlp_fwd", "mlp_fwd", 2 * P * (Cin + Cout), x,
+                   _ptr(x), P, Cin, Cout, nseg, _ptr(ss_in), float(slope_in), _ptr(W), w_per_seg, _ptr(y), float(eps),
+                   float(momentum), _ptr(running_mean), _ptr(running_var), _ptr(num_batches_tracked), _ptr(mean_shift),
+                   _ptr(gamma_out), _ptr(beta_out), _ptr(mean), _ptr(rstd), _ptr(ss_out), _ptr(ws))
+        return y, mean, rstd, ss_out
+
+    def rowbn_stats(self, x, eps, momentum, running_mean, running_var, num_batches_tracked, nseg, mean_shift):
+        """Training-mode batch statistics of x (P,C) alone (the reduction half of rowbn_fwd): mean, rstd
+        (nseg,C); running statistics / batch counter updated like nn.BatchNorm's forward."""
+        P, Cc = x.shape
+        mean = torch.empty((nseg, Cc), dtype=torch.float32, device=x.device)
+        rstd = torch.empty((nseg, Cc), dtype=torch.float32, device=x.device)
+        ws = self._bn_ws(x, Cc, nseg)
+        self._call("tpg_rowbn_fwd", "rowbn_fwd_stats", x.element_size() * P * Cc, x,
+                   _ptr(x), _DTYPE_CODE[x.dtype], P, 0, Cc, float(eps), float(momentum), 1, _ptr(running_mean),
+                   _ptr(running_var), _ptr(num_batches_tracked), _ptr(mean_shift), None, None, 1.0, _ptr(mean),
+                   _ptr(rstd), _ptr(x), _DTYPE_CODE[x.dtype], None, _ptr(ws), int(nseg), 1)
+        return mean, rstd
+
+    def rowbn_apply_max(self, x, K, mean, rstd, gamma, beta, slope, out_dtype, nseg):
+        """The streaming half of rowbn_fwd with GIVEN training-mode statistics: lrelu(BN(x)) [+ max over K]."""
+        P, Cc = x.shape
+        rows = P // K if K else P
+        y = torch.empty((rows, Cc), dtype=out_dtype, device=x.device)
+        arg = torch.empty((rows, Cc), dtype=torch.uint8, device=x.device) if K else None
+        ws = self._bn_ws(x, Cc, nseg)
+        self._call("tpg_rowbn_fwd", "rowbn_fwd_apply_max" if K else "rowbn_fwd_apply",
+                   x.element_size() * P * Cc + y.element_size() * rows * Cc + (rows * Cc if K else 0), x,
+                   _ptr(x), _DTYPE_CODE[x.dtype], P, K, Cc, 0.0, 0.0, 1, None, None, None, None, _ptr(gamma), _ptr(beta),
+                   float(slope), _ptr(mean), _ptr(rstd), _ptr(y), _DTYPE_CODE[out_dtype], _ptr(arg), _ptr(ws), int(nseg), 2)
+        return y, arg
+
+    def rowbn_bwd_sums(self, gy, x, arg, y, K, mean, rstd, gamma, beta, slope, need_affine, nseg):
+        """Backward sums of a training-mode BatchNorm (+LeakyReLU, + max over K): c12 (nseg,2,C) and, if
+        wanted, dgamma / dbeta."""
+        P, Cc = x.shape
+        c12 = torch.empty((nseg, 2, Cc), dtype=torch.float32, device=x.device)
+        dgamma = torch.empty(Cc, dtype=torch.float32, device=x.device) if need_affine else None
+        dbeta = torch.empty(Cc, dtype=torch.float32, device=x.device) if need_affine else None
+        ws = self._bn_ws(x, Cc, nseg)
+        if y is not None and (not K or y.dtype != gy.dtype):
+            y = None
+        self._call("tpg_rowbn_bwd_sums", "rowbn_bwd_reduce", 2 * gy.element_size() * gy.numel(), x,
+                   _ptr(gy), _DTYPE_CODE[gy.dtype], _ptr(x), _DTYPE_CODE[x.dtype], _ptr(arg), _ptr(y),
+                   _DTYPE_CODE[y.dtype] if y is not None else 0, P, K, Cc, 1, _ptr(mean), _ptr(rstd), _ptr(gamma),
+                   _ptr(beta), float(slope), _ptr(dgamma), _ptr(dbeta), _ptr(c12), _ptr(ws), int(nseg))
+        return c12, dgamma, dbeta
+
+    def mlp_consts(self, mean, rstd, gamma, beta, c12, want_ci, want_cb):
+        nseg, Cc = mean.shape
+        ci = torch.empty((nseg, 4, Cc), dtype=torch.float32, device=mean.device) if want_ci else None
+        cb = torch.empty((nseg, 4, Cc), dtype=torch.float32, device=mean.device) if want_cb else None
+        self._call("tpg_mlp_consts", "mlp_consts", 32 * nseg * Cc, mean, _ptr(mean), _ptr(rstd), _ptr(gamma), _ptr(beta),
+                   _ptr(c12), Cc, nseg, _ptr(ci), _ptr(cb))
+        return ci, cb
+
+    def mlp_dgrad(self, x_out, g_out, arg, K, cb_out, slope_out, x_in, ci_in, slope_in, W, nseg, need_affine):
+        """-> g_in (P,Cin) bf16, c12_in (nseg,2,Cin), dgamma_in, dbeta_in."""
+        P, Cout = x_out.shape
+        Cin = x_in.shape[1]
+        mode = 1 if arg is not None else 0
+        w_per_seg = int(W.dim() == 3 and W.shape[0] == nseg and nseg > 1)
+        g_in = torch.empty((P, Cin), dtype=torch.bfloat16, device=x_out.device)
+        c12 = torch.empty((nseg, 2, Cin), dtype=torch.float32, device=x_out.device)
+        dgamma = torch.empty(Cin, dtype=torch.float32, device=x_out.device) if need_affine else None
+        dbeta = torch.empty(Cin, dtype=torch.float32, device=x_out.device) if need_affine else None
+        ws = self._mlp_ws(x_out, max(Cin, Cout), nseg)
+        self._call("tpg_mlp_dgrad", "mlp_dgrad", 2 * P * (Cout + 2 * Cin) + (0 if mode else 2 * P * Cout), x_out,
+                   _ptr(x_out), _ptr(g_out), _ptr(arg), int(K), _ptr(cb_out), float(slope_out), _ptr(x_in), _ptr(ci_in),
+                   float(slope_in), _ptr(W), w_per_seg, P, Cin, Cout, nseg, mode, _ptr(g_in), _ptr(c12), _ptr(dgamma),
+                   _ptr(dbeta), _ptr(ws))
+        return g_in, c12, dgamma, dbeta
+
+    def mlp_wgrad(self, x_out, g_out, arg, K, cb_out, slope_out, x_in, ci_in, slope_in, nseg):
+        """-> dW (nseg,Cout,Cin) f32."""
+        P, Cout = x_out.shape
+        Cin = x_in.shape[1]
+        mode = 1 if arg is not None else 0
+        dW = torch.empty((nseg, Cout, Cin), dtype=torch.float32, device=x_out.device)
+        need = self.lib.tpg_mlp_wgrad_workspace_bytes(P, Cin, Cout, nseg) // 4
+        key = ("wgrad", x_out.device, torch.cuda.current_stream(x_out.device).cuda_stream)
+        ws = self._ws.get(key)
+        if ws is None or ws.numel() < need:
+            ws = torch.empty(need, dtype=torch.float32, device=x_out.device)
+            self._ws[key] = ws
+        self._call("tpg_mlp_wgrad", "mlp_wgrad", 2 * P * (Cout + Cin) + (0 if mode else 2 * P * Cout), x_out,
+                   _ptr(x_out), _ptr(g_out), _ptr(arg), int(K), _ptr(cb_out), float(slope_out), _ptr(x_in), _ptr(ci_in),
+                   float(slope_in), P, Cin, Cout, nseg, mode, _ptr(dW), _ptr(ws))
+        return dW
+
+    def mlp_bn_bwd_apply(self, g, x, ci, c12, nseg):
+        P, Cc = x.shape
+        dx = torch.empty_like(x)
+        self._call("tpg_mlp_bn_bwd_apply", "mlp_bn_bwd_apply", 6 * P * Cc, x, _ptr(g), _ptr(x), _ptr(ci), _ptr(c12), P,
+                   Cc, nseg, _ptr(dx))
+        return dx
+
     # ---- fused spectral norm (csrc/spectral.hip) ------------------------------------------
     def spectral_norm_fwd(self, W, u, v, iterate, eps):
         R, Cn = W.shape
@@ -855,6 +980,136 @@ def row_act_max(x, slope, K, out_dtype=None):
     the k neighbours] tail of an EdgeConv MLP (gcn_lib/pointnet/gcn.py:211) in one pass, with a
     one-pass backward (same kernels as row_bn_act with identity statistics)."""
     return row_bn_act(x, None, None, None, None, False, 0.0, 0.0, slope, K, out_dtype)
+
+
+# ------------------------------------------------------ fused MLP tail on MFMA tiles (bf16 rows)
+MLP_CHANNELS = ((64, 64), (64, 128), (128, 64), (128, 128), (128, 256), (256, 128), (256, 256))
+
+
+class _MlpTail(torch.autograd.Function):
+    """[BN_0 + act] -> W_1 -> [BN_1 + act] -> ... -> W_L -> [BN_L + act (+ max over K)] on bf16 rows, every
+    BatchNorm in training mode, `nseg` calls of the tail in one pass (csrc/mlp_fused.hip).
+
+    forward : statistics of x_0 (one read), then per layer ONE fused launch (BatchNorm + LeakyReLU in the
+              MFMA operand prologue, statistics of the product in the epilogue), then the final apply / max.
+    backward: per layer a data-gradient launch (dx_{l+1} rebuilt in the prologue, BN_l's backward sums in
+              the epilogue) and -- only where a weight needs its gradient -- a weight-gradient launch on
+              the same saved rows; nothing but the bf16 pre-BatchNorm rows x_l was ever stored.
+    tensors = gamma_0, beta_0, [W_l, gamma_l, beta_l]*L;  bns = the L+1 BatchNorm modules' state."""
+
+    @staticmethod
+    def forward(ctx, x0, cfg, *tensors):
+        nseg, K, slopes, eps, moms, states, shifts = cfg
+        be = backend_for(x0)
+        L = (len(tensors) - 2) // 3
+        gam = [tensors[0]] + [tensors[3 * l + 3] for l in range(L)]
+        bet = [tensors[1]] + [tensors[3 * l + 4] for l in range(L)]
+        Ws = [tensors[3 * l + 2] for l in range(L)]
+        xs, means, rstds = [x0], [], []
+        rm, rv, nbt = states[0]
+        m0, r0 = be.rowbn_stats(x0, eps[0], moms[0], rm, rv, nbt, nseg, shifts[0])
+        means.append(m0)
+        rstds.append(r0)
+        ss = be.mlp_scale_shift(m0, r0, gam[0], bet[0], x0.shape[1], nseg, x0)
+        for l in range(L):
+            rm, rv, nbt = states[l + 1]
+            y, m, r, ss = be.mlp_fwd(xs[-1], ss, slopes[l], Ws[l], nseg, eps[l + 1], moms[l + 1], rm, rv, nbt,
+                                     shifts[l + 1], gam[l + 1], bet[l + 1])
+            xs.append(y)
+            means.append(m)
+            rstds.append(r)
+        out, arg = be.rowbn_apply_max(xs[-1], K, means[-1], rstds[-1], gam[-1], bet[-1], slopes[L], torch.bfloat16, nseg)
+        ctx.save_for_backward(*xs, *means, *rstds, *[g for g in gam], *[b for b in bet], *Ws, out,
+                              *([arg] if arg is not None else []))
+        ctx.cfg = (nseg, K, slopes, L)
+        return out
+
+    @staticmethod
+    def backward(ctx, gout):
+        nseg, K, slopes, L = ctx.cfg
+        t = list(ctx.saved_tensors)
+        n = L + 1
+        xs, means, rstds, gam, bet = t[:n], t[n:2 * n], t[2 * n:3 * n], t[3 * n:4 * n], t[4 * n:5 * n]
+        Ws = t[5 * n:5 * n + L]
+        out = t[5 * n + L]
+        arg = t[5 * n + L + 1] if K else None
+        be = backend_for(xs[0])
+        gout = gout.contiguous()
+        if gout.dtype != torch.bfloat16:
+            gout = gout.to(torch.bfloat16)
+        # which gradients are wanted: (x0, cfg, gamma_0, beta_0, [W, gamma, beta]*L)
+        need = ctx.needs_input_grad
+        need_aff = [need[2] or need[3]] + [need[3 * l + 6 - 1] or need[3 * l + 6] for l in range(L)]
+        need_w = [need[3 * l + 4] for l in range(L)]
+        grads_aff = [None] * n
+        grads_w = [None] * L
+        # the last BatchNorm (+ act, + max): its sums come from (gout, out) alone
+        c12, dg, db = be.rowbn_bwd_sums(gout, xs[L], arg, out if K else None, K, means[L], rstds[L], gam[L], bet[L],
+                                        slopes[L], need_aff[L], nseg)
+        grads_aff[L] = (dg, db)
+        if L == 0:
+            raise RuntimeError("_MlpTail needs at least one fused layer")
+        g_next, arg_next, K_next = gout, arg, K
+        for l in range(L, 0, -1):                    # layer l: x_{l-1} -> x_l
+            _, cb = be.mlp_consts(means[l], rstds[l], gam[l], bet[l], c12, False, True)
+            ci, _ = be.mlp_consts(means[l - 1], rstds[l - 1], gam[l - 1], bet[l - 1], None, True, False)
+            if l == L and not K:
+                # no max: the "arriving gradient" is dense but NOT yet activated; activate it here
+                raise RuntimeError("_MlpTail without the max over K is not wired")
+            if need_w[l - 1]:
+                grads_w[l - 1] = be.mlp_wgrad(xs[l], g_next, arg_next, K_next, cb, slopes[l], xs[l - 1], ci, slopes[l - 1],
+                                              nseg)
+            g_in, c12, dg, db = be.mlp_dgrad(xs[l], g_next, arg_next, K_next, cb, slopes[l], xs[l - 1], ci, slopes[l - 1],
+                                             Ws[l - 1], nseg, need_aff[l - 1])
+            grads_aff[l - 1] = (dg, db)
+            g_next, arg_next, K_next = g_in, None, 0
+        dx0 = be.mlp_bn_bwd_apply(g_next, xs[0], ci, c12, nseg) if need[0] else None
+        res = [dx0, None, grads_aff[0][0], grads_aff[0][1]]
+        for l in range(L):
+            gw = grads_w[l]
+            if gw is not None and Ws[l].dim() == 2:
+                gw = gw.sum(0) if gw.shape[0] > 1 else gw[0]
+            elif gw is not None and Ws[l].shape[0] != gw.shape[0]:
+                gw = gw.sum(0, keepdim=True)
+            res += [gw, grads_aff[l + 1][0], grads_aff[l + 1][1]]
+        return tuple(res)
+
+
+def mlp_tail_supported(x, channels, K):
+    """Can `mlp_tail` run this tail?  bf16 rows on the GPU, supported channel pairs, a max over K."""
+    if not (x.is_cuda and x.dtype == torch.bfloat16 and 0 < K <= 256 and len(channels) >= 2):
+        return False
+    return all((a, b) in MLP_CHANNELS for a, b in zip(channels[:-1], channels[1:]))
+
+
+def mlp_tail(x0, bns, weights, slopes, K, nseg=1, shifts=None):
+    """The tail of a shared MLP on bf16 rows x0 (P, C_0), fused on MFMA tiles (csrc/mlp_fused.hip):
+
+        out = max_K lrelu(BN_L(W_L ... lrelu(BN_1(W_1 lrelu(BN_0(x0))))))          (P/K, C_L) bf16
+
+    bns: the L+1 BatchNorm modules (training mode, fixed momentum; state updated like their own forward),
+    weights: L tensors (C_l, C_{l-1}) or (nseg, C_l, C_{l-1}) fp32 (e.g. successive spectral-norm iterates),
+    slopes: L+1 LeakyReLU slopes, nseg: calls of the tail on equal consecutive row blocks,
+    shifts: per BatchNorm an optional bias of the preceding conv that was left out of its input."""
+    L = len(weights)
+    _need(len(bns) == L + 1 and len(slopes) == L + 1 and L >= 1, "mlp_tail: L weights, L+1 BatchNorms / slopes")
+    shifts = list(shifts) if shifts is not None else [None] * (L + 1)
+    states, eps, moms = [], [], []
+    for bn in bns:
+        _need(bn.training and bn.momentum is not None, "mlp_tail needs training-mode BatchNorm with a fixed momentum")
+        track = bn.track_running_stats and bn.running_mean is not None
+        states.append((bn.running_mean if track else None, bn.running_var if track else None,
+                       bn.num_batches_tracked if (track and bn.num_batches_tracked is not None) else None))
+        eps.append(float(bn.eps))
+        moms.append(float(bn.momentum))
+    tensors = [bns[0].weight.float(), bns[0].bias.float()]
+    for l in range(L):
+        w = weights[l]
+        _need(w.dtype == torch.float32, "mlp_tail weights are fp32 (rounded to bf16 inside the kernel)")
+        tensors += [w.contiguous(), bns[l + 1].weight.float(), bns[l + 1].bias.float()]
+    cfg = (int(nseg), int(K), tuple(float(s) for s in slopes), tuple(eps), tuple(moms), tuple(states),
+           tuple(None if s is None else s.detach().float().contiguous() for s in shifts))
+    return _MlpTail.apply(x0.contiguous(), cfg, *tensors)
 
 
 # ---------------------------------------------------------------------- fused spectral norm

@@ -198,8 +198,22 @@ def capture_losses():
 
 
 # --------------------------------------------------------------------------- train steps
-def step_fixture(kind):
-    out = {}
+# Stability probe: relative coordinate jitter and the loss change a seed may show under it.
+# 1e-7 = fp32 rounding: what another summation order (another BLAS, a GPU) does to the inputs of
+# the discrete decisions.  (At 3e-5 -- the size of what this repo's default order, first layer
+# before the gather, does to the generator's output: W f_j - W f_i against W (f_j - f_i) rounds
+# relative to |f|, not to |f_j - f_i| -- NO seed of 12 was stable: every clip moved some GAN loss by
+# 6-20 %.  The GAN terms of an untrained step are chaotic at that level, which is why the default
+# order is pinned piecewise -- generator, discriminators, losses, gradients of both orders -- and
+# only the reference order is pinned on whole steps.)
+JITTER = 1e-7
+STABLE = 2e-5
+STEP_BATCH = 4    # clips per step fixture: with 2 the heads' BatchNorm1d sees xhat = +-1 (a sign network)
+
+
+def _ref_step(kind, clip_seed, noise_seed=None):
+    """One step of the reference from seeded state on the seeded clip; noise_seed: the clip's
+    coordinates multiplied by (1 + JITTER * N(0,1)) first (stability probe, see step_fixture)."""
     if kind == "action":
         torch.manual_seed(40)
         G = ref_net.NoMaskSRNet(3, 128, upsample_ratio=16)
@@ -207,7 +221,7 @@ def step_fixture(kind):
         Ds = ref_dis.ActionSpatialDis()
         torch.manual_seed(42)
         Dt = ref_dis.ActionTempoDis(3)
-        low, high = action_clip(2, 2048, 16, 3, seed=30)
+        low, high = action_clip(STEP_BATCH, 2048, 16, 3, seed=clip_seed)
         opt = Namespace(R=2.0, w=2.0)
     else:
         torch.manual_seed(30)
@@ -218,12 +232,13 @@ def step_fixture(kind):
         Dt = ref_dis.FluidTempoDis(3)
         if kind == "fluid_keep":
             set_mask_head(G, "keep", 0)
-        low, high = fluid_clip(2, 1024, 8, 3, seed=31)
+        low, high = fluid_clip(STEP_BATCH, 1024, 8, 3, seed=clip_seed)
         opt = Namespace(use_vel=False, in_node_feats=3, cutoff=0.025, R=0.10, w=0.5)
-    for tag, m in (("G", G), ("Ds", Ds), ("Dt", Dt)):
-        out.update(pack(f"w/{tag}", checksums(m)))
-    out["low"] = np.stack([n(x) for x in low])
-    out["high"] = np.stack([n(x) for x in high])
+    if noise_seed is not None:
+        g = torch.Generator().manual_seed(noise_seed)
+        low = [x * (1 + JITTER * torch.randn(x.shape, generator=g)) for x in low]
+        high = [x * (1 + JITTER * torch.randn(x.shape, generator=g)) for x in high]
+    before = {tag: checksums(m) for tag, m in (("G", G), ("Ds", Ds), ("Dt", Dt))}
     # plain SGD so that parameter deltas are proportional to the gradients being compared
     og = torch.optim.SGD(G.parameters(), lr=0.05)
     ot = torch.optim.SGD(Dt.parameters(), lr=0.05)
@@ -235,9 +250,45 @@ def step_fixture(kind):
     else:
         losses = ref_step.tempo_gan_step(G, Ds, Dt, list(low), None, list(high), None, 1.0, opt, 12,
                                          og, ot, os_)
+    return losses, before, (G, Ds, Dt), low, high
+
+
+def step_fixture(kind, first_seed=31, tries=12):
+    """A full adversarial step of the reference: losses + parameters after one SGD step.
+
+    The GAN terms of a step of UNTRAINED networks can sit on a discrete decision (an FPS pick, a
+    ball-query membership, a max-pool winner on the generated clouds) that a rounding-level change
+    of the coordinates flips, moving a loss by 1e-2: measured on the first fixture of this repo
+    (two clips, seed 31), whose `tempo_G_loss` read 0.96814 or 0.94807 under a 1e-7 jitter of the
+    inputs -- and with two clips the heads' BatchNorm1d is a sign network on top of that.  Such a
+    clip pins nothing but the reference's own summation order.  So the fixtures hold four clips
+    and the clip seed is SELECTED: the first one for which three runs of the reference with
+    coordinates jittered by JITTER reproduce every loss of the clean run to STABLE (the steadiest of
+    `tries` seeds otherwise; the measured sensitivity is stored as `jitter_sensitivity`).  Any
+    faithful implementation (other GEMM order, other device, first layer before the gather) then
+    lands on the same decisions."""
+    best = None
+    for clip_seed in range(first_seed, first_seed + tries):
+        losses = _ref_step(kind, clip_seed)[0]
+        worst = 0.0
+        for noise_seed in (1, 2, 3):
+            jl = _ref_step(kind, clip_seed, noise_seed)[0]
+            worst = max(worst, max(abs(jl[k] - losses[k]) / max(1.0, abs(losses[k])) for k in losses))
+        print(f"{kind}: clip seed {clip_seed}: worst loss change under {JITTER:g} jitter {worst:.2e}", flush=True)
+        if best is None or worst < best[0]:
+            best = (worst, clip_seed)
+        if worst <= STABLE:
+            break
+    worst, clip_seed = best
+    losses, before, nets, low, high = _ref_step(kind, clip_seed)
+    out = {"clip_seed": np.int64(clip_seed), "jitter_sensitivity": np.float64(worst)}
+    for tag in ("G", "Ds", "Dt"):
+        out.update(pack(f"w/{tag}", before[tag]))
+    out["low"] = np.stack([n(x) for x in low])
+    out["high"] = np.stack([n(x) for x in high])
     for k, v in losses.items():
         out[f"loss/{k}"] = np.float64(v)
-    for tag, m in (("G", G), ("Ds", Ds), ("Dt", Dt)):
+    for tag, m in zip(("G", "Ds", "Dt"), nets):
         out.update(pack(f"w_after/{tag}", checksums(m)))
     print(kind, losses)
     save(f"step_{kind}", **out)

@@ -1,0 +1,190 @@
+"""The fused MFMA tail-layer kernels (csrc/mlp_fused.hip) against a plain PyTorch fp32 statement of
+the same op on the same (bf16-rounded) inputs.
+
+Tolerances: the kernel multiplies bf16 operands exactly and accumulates in fp32 like the reference
+product; the stored y is rounded once to bf16, so |y - y_ref| <= one bf16 ulp of |y_ref| (2^-8
+relative) plus the fp32 summation-order noise; statistics are computed from the kernel's OWN
+stored values and must match an fp64 recomputation from them to 1e-5."""
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def hip():
+    import tpgan_amd.ops as ops
+    return ops.backend_for(torch.zeros(1, device="cuda"))
+
+
+def _layer_inputs(P, Cin, Cout, nseg, seed, with_bn=True):
+    g = torch.Generator().manual_seed(seed)
+    x = (torch.randn(P, Cin, generator=g) * 0.7 + 0.3 * torch.randn(1, Cin, generator=g)).bfloat16().cuda()
+    W = (torch.randn(nseg, Cout, Cin, generator=g) / Cin ** 0.5).cuda()
+    if with_bn:
+        ss = torch.stack([torch.rand(nseg, Cin, generator=g) + 0.5, 0.3 * torch.randn(nseg, Cin, generator=g)], 1).cuda()
+    else:
+        ss = None
+    return x, W, ss
+
+
+def _ref_fwd(x, W, ss, slope, nseg):
+    P = x.shape[0] // nseg
+    ys = []
+    for s in range(nseg):
+        a = x[s * P:(s + 1) * P].float()
+        if ss is not None:
+            # one rounding of the exact x*sc + sh, like the kernel's fma
+            a = (a.double() * ss[s, 0].double() + ss[s, 1].double()).float()
+        a = torch.where(a > 0, a, a * slope).bfloat16().float()
+        ys.append(a @ W[s].bfloat16().float().t())
+    return torch.cat(ys, 0)
+
+
+@pytest.mark.parametrize("Cin,Cout", [(64, 64), (64, 128), (128, 64), (128, 128), (128, 256), (256, 128), (256, 256)])
+@pytest.mark.parametrize("P,nseg", [(8 * 128 * 32, 1), (3 * 4096, 3), (1000, 1), (2 * 16 * 7, 2)])
+def test_mlp_fwd_matches_torch(hip, Cin, Cout, P, nseg):
+    x, W, ss = _layer_inputs(P, Cin, Cout, nseg, seed=Cin + Cout + P)
+    rm, rv = torch.zeros(Cout, device="cuda"), torch.ones(Cout, device="cuda")
+    nbt = torch.zeros((), dtype=torch.int64, device="cuda")
+    gamma, beta = torch.rand(Cout, device="cuda") + 0.5, torch.randn(Cout, device="cuda") * 0.1
+    y, mean, rstd, ss_out = hip.mlp_fwd(x, ss, 0.01, W, nseg, 1e-5, 0.1, rm, rv, nbt, None, gamma, beta)
+    ref = _ref_fwd(x, W, ss, 0.01, nseg)
+    err = (y.float() - ref).abs()
+    # same bf16 operands, fp32 accumulation in another order, ONE rounding of y to bf16: within one
+    # bf16 ulp (2^-7 relative: a sum that lands next to a rounding tie may go to the other neighbour)
+    bound = ref.abs() * 2.0 ** -7 + 1e-5 * ref.abs().max()
+    assert bool((err <= bound).all()), float((err - bound).max())
+    # statistics of the stored tensor, per segment
+    Ps = P // nseg
+    yd = y.double().view(nseg, Ps, Cout)
+    m_ref, v_ref = yd.mean(1), yd.var(1, unbiased=False)
+    assert torch.allclose(mean.double(), m_ref, rtol=0, atol=1e-5 * float(m_ref.abs().max() + v_ref.sqrt().max()))
+    assert torch.allclose(rstd.double(), (v_ref + 1e-5).rsqrt(), rtol=1e-5, atol=0)
+    a = gamma * rstd
+    assert torch.allclose(ss_out[:, 0], a) and torch.allclose(ss_out[:, 1], beta - mean * a, atol=1e-6)
+    # running statistics chained segment after segment, unbiased variance, counter += nseg
+    erm, erv = torch.zeros(Cout, dtype=torch.float64), torch.ones(Cout, dtype=torch.float64)
+    for s in range(nseg):
+        erm = 0.9 * erm + 0.1 * m_ref[s].cpu()
+        erv = 0.9 * erv + 0.1 * (v_ref[s].cpu() * Ps / (Ps - 1))
+    assert torch.allclose(rm.double().cpu(), erm, atol=1e-5) and torch.allclose(rv.double().cpu(), erv, rtol=1e-5, atol=1e-6)
+    assert int(nbt) == nseg
+
+
+def test_mlp_fwd_statistics_survive_a_large_mean(hip):
+    """|mean| / sigma = 1e3 in the OUTPUT: the pivoted, Chan-combined sums keep the variance."""
+    P, Cin, Cout = 65536, 64, 128
+    x = torch.ones(P, Cin).bfloat16().cuda()
+    x[:, 0] = (torch.randn(P) * 0.01).bfloat16().cuda()             # the only varying input
+    W = torch.zeros(1, Cout, Cin).cuda()
+    W[0, :, 1] = 8.0                                                  # constant part: 8
+    W[0, :, 0] = 1.0                                                  # varying part: sigma 0.01
+    y, mean, rstd, _ = hip.mlp_fwd(x, None, 1.0, W, 1, 1e-5, 0.0, None, None, None, None, None, None)
+    yd = y.double()
+    assert torch.allclose(mean.double()[0], yd.mean(0), atol=1e-6)
+    assert torch.allclose(rstd.double()[0], (yd.var(0, unbiased=False) + 1e-5).rsqrt(), rtol=1e-4)
+
+
+def test_mlp_fwd_is_bitwise_reproducible(hip):
+    x, W, ss = _layer_inputs(6 * 8192, 64, 128, 3, seed=5)
+    a = hip.mlp_fwd(x, ss, 0.2, W, 3, 1e-5, 0.1, None, None, None, None, None, None)
+    b = hip.mlp_fwd(x, ss, 0.2, W, 3, 1e-5, 0.1, None, None, None, None, None, None)
+    for u, v in zip(a, b):
+        assert torch.equal(u, v)
+
+
+# ------------------------------------------------------------------ the whole tail, forward + backward
+def _ste_bf16(t):
+    """bf16 rounding with a straight-through gradient: the reference rounds where the kernels round."""
+    return t + (t.bfloat16().float() - t).detach()
+
+
+def _ref_tail(x0, gammas, betas, Ws, slopes, K, nseg, eps=1e-5):
+    outs = []
+    P = x0.shape[0] // nseg
+    for s in range(nseg):
+        a = x0[s * P:(s + 1) * P]
+        for l in range(len(gammas)):
+            m, v = a.mean(0), a.var(0, unbiased=False)
+            z = (a - m) * (gammas[l] * (v + eps).rsqrt()) + betas[l]
+            a = torch.where(z > 0, z, z * slopes[l])
+            if l < len(Ws):
+                w = Ws[l][s] if Ws[l].dim() == 3 else Ws[l]
+                a = _ste_bf16(_ste_bf16(a) @ _ste_bf16(w).t())       # operands and the stored product in bf16
+        outs.append(a.view(P // K, K, -1).max(1)[0])
+    return torch.cat(outs, 0)
+
+
+def _rel(a, b):
+    return float((a.double() - b.double()).norm() / b.double().norm().clamp_min(1e-12))
+
+
+@pytest.mark.parametrize("chain,K,P,nseg,per_seg_w", [
+    ((64, 128), 32, 8 * 64 * 32, 1, False), ((64, 128), 32, 2 * 8 * 64 * 32, 2, True),
+    ((128, 128), 32, 4096, 1, False), ((128, 256), 16, 3 * 2048, 3, True),
+    ((256, 128, 256), 32, 2 * 4096, 2, True), ((256, 256, 256), 32, 4096, 1, False),
+    ((64, 64, 128), 64, 4096, 1, False), ((128, 64), 8, 1000 * 8, 1, False)])
+def test_mlp_tail_forward_backward(chain, K, P, nseg, per_seg_w):
+    import tpgan_amd.ops as ops
+    torch.manual_seed(sum(chain) + K)
+    L = len(chain) - 1
+    x0 = (torch.randn(P, chain[0]) * 0.8 + 0.2 * torch.randn(1, chain[0])).bfloat16().cuda()
+    bns = [torch.nn.BatchNorm1d(c).cuda().train() for c in chain]
+    for bn in bns:
+        with torch.no_grad():
+            bn.weight.uniform_(0.5, 1.5)
+            bn.bias.normal_(0, 0.2)
+    Ws = [(torch.randn(*((nseg,) if per_seg_w else ()), chain[l + 1], chain[l]) / chain[l] ** 0.5).cuda().requires_grad_(True)
+          for l in range(L)]
+    slopes = [0.01] * (L + 1)
+    assert ops.mlp_tail_supported(x0, chain, K)
+    xk = x0.clone().requires_grad_(True)
+    out = ops.mlp_tail(xk, bns, Ws, slopes, K, nseg)
+    gout = torch.randn(out.shape, device="cuda").bfloat16()
+    params = [xk] + Ws + [p for bn in bns for p in (bn.weight, bn.bias)]
+    got = torch.autograd.grad(out, params, gout)
+    xr = x0.float().clone().requires_grad_(True)
+    ref = _ref_tail(xr, [bn.weight for bn in bns], [bn.bias for bn in bns], Ws, slopes, K, nseg)
+    want = torch.autograd.grad(ref, [xr] + Ws + [p for bn in bns for p in (bn.weight, bn.bias)], gout.float())
+    # forward: the stored output is one bf16 rounding of a value that went through L bf16 products
+    err = float((out.float() - ref).abs().max() / ref.abs().max())
+    assert err <= 2e-2, err
+    # (a max-pool winner may differ where two rows are within rounding: compared in L2)
+    names = ["dx0"] + [f"dW{l + 1}" for l in range(L)] + [f"{n}{l}" for l in range(L + 1) for n in ("dgamma", "dbeta")]
+    for name, g, w in zip(names, got, want):
+        assert g.shape == w.shape, (name, g.shape, w.shape)
+        rel = _rel(g.float(), w)
+        assert rel <= 3e-2, (name, rel)
+    # running statistics moved like nn.BatchNorm's own forward (momentum 0.1, nseg updates)
+    assert all(int(bn.num_batches_tracked) == nseg for bn in bns)
+    assert all(not torch.equal(bn.running_mean, torch.zeros_like(bn.running_mean)) for bn in bns)
+
+
+def test_mlp_tail_frozen_weights_need_no_weight_gradient():
+    """The generator step back-propagates through FROZEN discriminators: data gradient only."""
+    import tpgan_amd.ops as ops
+    torch.manual_seed(0)
+    x0 = torch.randn(4096, 64).bfloat16().cuda().requires_grad_(True)
+    bns = [torch.nn.BatchNorm1d(c).cuda().train().requires_grad_(False) for c in (64, 128)]
+    W = (torch.randn(128, 64) / 8).cuda()
+    out = ops.mlp_tail(x0, bns, [W], [0.01, 0.01], 32)
+    (gx,) = torch.autograd.grad(out, [x0], torch.randn_like(out))
+    assert torch.isfinite(gx).all() and float(gx.abs().max()) > 0
+
+
+def test_mlp_tail_is_bitwise_reproducible():
+    import tpgan_amd.ops as ops
+    torch.manual_seed(1)
+    x0 = torch.randn(3 * 8192, 64).bfloat16().cuda()
+    W = (torch.randn(3, 128, 64) / 8).cuda().requires_grad_(True)
+    res = []
+    for _ in range(2):
+        bns = [torch.nn.BatchNorm1d(c).cuda().train() for c in (64, 128)]
+        xk = x0.clone().requires_grad_(True)
+        out = ops.mlp_tail(xk, bns, [W], [0.01, 0.01], 32, 3)
+        g = torch.autograd.grad(out, [xk, W, bns[0].weight, bns[1].bias], torch.ones_like(out))
+        res.append((out,) + tuple(g) + (bns[1].running_var.clone(),))
+    for a, b in zip(*res):
+        assert torch.equal(a, b)
