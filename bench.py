@@ -2,6 +2,7 @@
 4096-point x 3-frame fluid clips, batch 8 per GPU (BASELINE.json configs[1]; weak scaling).
 
     python bench.py --gpus 1 --steps 20 --warmup 3
+    python bench.py --config cfg4 | cfg5shard        # the other single-GPU workloads of BASELINE.json
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 \
         --master-port P bench.py --gpus N --steps K --warmup W
 
@@ -10,8 +11,11 @@ One "step" = `tempo_gan_step` semantics with generator AND both discriminators u
 resident in HBM before the timed region.  Rank 0 prints ONE JSON line.
 
 Extra legs (rank 0, N == 1 only):
-  roofline      the hand-written kernel with the largest share of kernel time, timed live
-                with HIP events on its launch stream inside a second run of the same steps;
+  roofline      the hand-written kernel with the largest TOTAL time among ALL hand-written kernels,
+                timed live with HIP events on its launch stream while the captured step body runs
+                launch by launch; `roofline_streaming` is the same for the largest HBM-streaming
+                kernel, `mfma` the matrix-core work (hand-written MFMA kernels and the remaining
+                library GEMMs: flops / time against the 2.5 PFLOP/s dense bf16 peak);
   cpu_baseline  the same step function on the host cores through the oracle ops (kind
                 "port": the reference has no CPU path for pointnet2_ops/FRNN), on a bounded
                 sample (4 clips instead of 8), scaled to the metric's unit.
@@ -21,7 +25,6 @@ import json
 import os
 import sys
 import time
-from argparse import Namespace
 
 import numpy as np
 import torch
@@ -31,11 +34,7 @@ if ROOT not in sys.path:
     sys.path.insert(0, ROOT)
 
 import tpgan_amd  # noqa: E402
-from tpgan_amd import ddp, ops  # noqa: E402
-from tpgan_amd.gan_step import tempo_gan_step  # noqa: E402
-from tpgan_amd.set_abstraction import FluidSpatialDis, FluidTempoDis  # noqa: E402
-from tpgan_amd.srnet import SRNet  # noqa: E402
-from tpgan_amd.synthetic import fluid_clip, force_all_keep  # noqa: E402
+from tpgan_amd import configs, ddp, ops  # noqa: E402
 
 T_START = time.perf_counter()
 
@@ -45,36 +44,21 @@ def log(msg):
     print(f"[bench +{time.perf_counter() - T_START:7.1f}s] {msg}", file=sys.stderr, flush=True)
 
 
-HBM_PEAK_GBPS = 8000.0   # MI355X spec, /opt/skills/guides/MI355X_MICROARCH.md
-OPT = Namespace(use_vel=False, in_node_feats=3, cutoff=0.025, R=0.10, w=0.5)
+HBM_PEAK_GBPS = 8000.0       # MI355X spec, /opt/skills/guides/MI355X_MICROARCH.md
+MFMA_PEAK_TFLOPS = 2500.0    # dense bf16, same guide (AMD's 5 PF figure is 2:1 sparse)
+CONFIG = "cfg2"
 
 
 def build(device, seed=1, capturable=False):
-    torch.manual_seed(seed)
-    G = force_all_keep(SRNet(3, 128)).to(device)
-    Ds = FluidSpatialDis().to(device)
-    Dt = FluidTempoDis(3).to(device)
-    lr = 3e-4
-    # capturable for the hipGraph path; fused = torch's single-launch multi-tensor Adam (the
-    # foreach form divides by per-parameter 0-dim step tensors one launch per parameter)
-    kw = {"capturable": True, "fused": torch.device(device).type == "cuda"} if capturable else {}
-
-    def adam(params, lr_):
-        try:
-            return torch.optim.Adam(params, lr=lr_, **kw)
-        except (RuntimeError, ValueError):
-            return torch.optim.Adam(params, lr=lr_, **{k: v for k, v in kw.items() if k != "fused"})
-    opts = (adam(list(G.parameters()), lr), adam(list(Dt.parameters()), 0.33 * lr), adam(list(Ds.parameters()), 0.33 * lr))
-    return G, Ds, Dt, opts
+    return configs.build_models(CONFIG, device, seed=seed, capturable=capturable)
 
 
-GRAPHED = None   # GraphedFluidStep when the hipGraph path is active
+GRAPHED = None   # GraphedFluidStep / GraphedActionStep when the hipGraph path is active
 EAGER_BODY = False   # --eager-body: run the captured step body launch by launch (for PMC passes)
 TRACE = bool(os.environ.get("TPGAN_BENCH_TRACE"))
 
 
 def run_steps(models, clips, n, sync, amp_dtype, start=0):
-    G, Ds, Dt, (og, ot, os_) = models
     out = None
     for i in range(n):
         low, high = clips[(start + i) % len(clips)]
@@ -83,8 +67,7 @@ def run_steps(models, clips, n, sync, amp_dtype, start=0):
         elif GRAPHED is not None and low[0].is_cuda:
             out = GRAPHED(low, high, 12)
         else:
-            out = tempo_gan_step(G, Ds, Dt, low, None, high, None, 1.0, OPT, 12, og, ot, os_,
-                                 sync=sync, amp_dtype=amp_dtype, force_gate=True)
+            out = configs.eager_step(CONFIG, models, (low, high), 12, sync=sync, amp_dtype=amp_dtype)
         if TRACE:
             log("step %d: %s" % (start + i, {k: round(v, 4) for k, v in out.items()}))
     return out
@@ -102,9 +85,10 @@ def cpu_baseline(sample_batch, per_gpu_batch, n_hi):
         torch.set_num_threads(cores)
         np.random.seed(0)
         models = build("cpu")
-        warm = [fluid_clip(2, 512, 8, 3, seed=7)]
+        spec = configs.SPECS[CONFIG]
+        warm = [configs.make_clip(CONFIG, batch=2, points=512 if spec["kind"] == "fluid" else 1024, seed=7)]
         run_steps(models, warm, 1, None, None)                      # page in / thread pools
-        clips = [fluid_clip(sample_batch, n_hi, 8, 3, seed=1234)]
+        clips = [configs.make_clip(CONFIG, batch=sample_batch, points=n_hi, seed=1234)]
         t0 = time.perf_counter()
         run_steps(models, clips, 1, None, None)
         dt = time.perf_counter() - t0
@@ -112,7 +96,7 @@ def cpu_baseline(sample_batch, per_gpu_batch, n_hi):
         torch_backend.uninstall()
     return {"value": (sample_batch / per_gpu_batch) / dt, "unit": "steps/s", "cores": cores,
             "kind": "port",
-            "sample": f"1 full G+D step on {sample_batch} clips of {n_hi} pts x3 frames "
+            "sample": f"1 full G+D step on {sample_batch} clips of {n_hi} pts x{configs.SPECS[CONFIG]['frames']} frames "
                       f"({dt:.1f} s), scaled by {sample_batch}/{per_gpu_batch} to the batch-"
                       f"{per_gpu_batch} step; fp32; oracle C ops (OpenMP) + CPU PyTorch convs"}
 
@@ -134,29 +118,66 @@ def roofline_leg(models, clips, steps, sync, amp_dtype):
         ops.set_timer(None)
         GRAPHED = saved
     summ = timer.summary()
-    # Streaming kernels are priced against the HBM roofline; furthest-point sampling and the
-    # neighbour searches are chains of dependent rounds on cache-resident clouds (latency /
-    # issue bound by construction) and are listed with their own figure instead.
-    streaming = [k for k in summ if k.startswith(("rowbn_", "rowcombine_", "group_"))]
-    name = max(streaming or list(summ), key=lambda k: summ[k]["total_ms"])
-    dom = summ[name]
-    roof = {"bound": "hbm", "kernel": name, "achieved": round(dom["gbps"], 2), "peak": HBM_PEAK_GBPS,
-            "unit": "GB/s", "frac": round(dom["gbps"] / HBM_PEAK_GBPS, 6), "traffic": pmc_traffic(name),
-            "avg_launch_us": round(dom["avg_us"], 2), "launches_per_step": dom["launches"] / steps,
-            "algorithmic_bytes_per_launch": int(dom["bytes_per_launch"]),
-            "selection": "largest total time among the HBM-streaming kernels; timed per launch with HIP "
-                         "events while the captured step body runs eagerly (launch by launch)"}
-    table = {k: {"launches_per_step": v["launches"] / steps, "ms_per_step": round(v["total_ms"] / steps, 4),
-                 "avg_us": round(v["avg_us"], 2), "GBps": round(v["gbps"], 1)} for k, v in summ.items()}
+    library = [k for k in summ if k.startswith("gemm_")]          # hipBLASLt through torch, not hand-written
+    hand = [k for k in summ if k not in library]
+    # Streaming kernels are priced against the HBM roofline.  Furthest-point sampling and the
+    # neighbour searches are chains of dependent rounds on cache-resident clouds (latency / issue
+    # bound by construction): they get the same arithmetic -- algorithmic bytes / time -- and a note.
+    streaming = [k for k in hand if k.startswith(("rowbn_", "rowcombine_", "group_", "mlp_"))]
+    steps_f = float(steps)
+
+    def roof(name, selection):
+        d = summ[name]
+        return {"bound": "hbm", "kernel": name, "achieved": round(d["gbps"], 2), "peak": HBM_PEAK_GBPS,
+                "unit": "GB/s", "frac": round(d["gbps"] / HBM_PEAK_GBPS, 6), "traffic": pmc_traffic(name),
+                "traffic_source": "profiles/%s (rocprofv3 PMC passes of the same step body; not re-measured in this run)"
+                                  % PMC_FILE,
+                "avg_launch_us": round(d["avg_us"], 2), "launches_per_step": d["launches"] / steps_f,
+                "ms_per_step": round(d["total_ms"] / steps_f, 4),
+                "algorithmic_bytes_per_launch": int(d["bytes_per_launch"]), "selection": selection}
+    dom = max(hand, key=lambda k: summ[k]["total_ms"])
+    roofline = roof(dom, "largest total time among ALL hand-written kernels; timed per launch with HIP events "
+                         "while the captured step body runs eagerly (launch by launch)")
+    if dom == "fps":
+        spec = configs.SPECS[CONFIG]
+        roofline["note"] = ("furthest-point sampling: npoint-1 dependent rounds per launch on one workgroup per cloud, "
+                            "bound by VALU issue + one barrier per round, not by bytes (DESIGN.md section 4: "
+                            "0.57 us/round at 4096 points); hidden on the index-plan streams in graph mode")
+        roofline["us_per_round"] = round(summ["fps"]["avg_us"] / max(1, spec["points"] // 4 - 1), 4)
+    line = {"roofline": roofline}
+    if streaming:
+        sdom = max(streaming, key=lambda k: summ[k]["total_ms"])
+        line["roofline_streaming"] = roof(sdom, "largest total time among the HBM-streaming hand-written kernels")
+    # matrix-core work: the hand-written MFMA kernels and what is left on the library
+    mf = {}
+    for grp, names in (("hand_written_mfma", [k for k in hand if k in ("mlp_fwd", "mlp_dgrad", "mlp_wgrad")]),
+                       ("library_gemm", library)):
+        fl = sum(summ[k]["flops_per_launch"] * summ[k]["launches"] for k in names)
+        ms = sum(summ[k]["total_ms"] for k in names)
+        if ms > 0:
+            mf[grp] = {"kernels": names, "tflop_per_step": round(fl / steps_f / 1e12, 4), "ms_per_step": round(ms / steps_f, 4),
+                       "achieved_tflops": round(fl / 1e12 / (ms / 1e3), 2),
+                       "frac_of_peak": round(fl / 1e12 / (ms / 1e3) / MFMA_PEAK_TFLOPS, 5)}
+    if mf:
+        mf["peak_tflops"] = MFMA_PEAK_TFLOPS
+        mf["note"] = ("bf16 MFMA, dense peak; these contractions run at 43-128 flop/B against a ridge of ~310 flop/B, "
+                      "i.e. they are HBM-bound by design (see roofline_streaming) and the matrix pipe idles")
+        line["mfma"] = mf
+    table = {k: {"launches_per_step": v["launches"] / steps_f, "ms_per_step": round(v["total_ms"] / steps_f, 4),
+                 "avg_us": round(v["avg_us"], 2), "GBps": round(v["gbps"], 1),
+                 **({"TFLOPs": round(v["tflops"], 1)} if v["flops_per_launch"] else {})} for k, v in summ.items()}
     if "fps" in summ:
         table["fps"]["note"] = "npoint-1 dependent rounds per launch; hidden on a side stream in graph mode"
-    return roof, table
+    return line, table
+
+
+PMC_FILE = "r02_pmc_traffic.json"
 
 
 def pmc_traffic(kernel):
     """HBM bytes per launch of `kernel` from the committed rocprofv3 PMC passes (profiles/), with the
     gfx950 FETCH_SIZE x2 correction for wide coalesced reads; None when no PMC file is present."""
-    path = os.path.join(ROOT, "profiles", "r01_pmc_traffic.json")
+    path = os.path.join(ROOT, "profiles", PMC_FILE)
     try:
         with open(path) as fh:
             rec = json.load(fh).get(kernel)
@@ -170,8 +191,10 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=3)
-    ap.add_argument("--batch", type=int, default=8, help="clips per GPU")
-    ap.add_argument("--points", type=int, default=4096, help="high-res points per frame")
+    ap.add_argument("--config", choices=sorted(configs.SPECS), default="cfg2",
+                    help="BASELINE.json workload (cfg2 = the headline metric; cfg3 is cfg2 on 8 ranks)")
+    ap.add_argument("--batch", type=int, default=None, help="clips per GPU (default: the workload's, 8)")
+    ap.add_argument("--points", type=int, default=None, help="high-res points per frame (default: the workload's)")
     ap.add_argument("--dtype", choices=["bf16", "fp32"], default="bf16")
     ap.add_argument("--no-extra", action="store_true", help="skip roofline and cpu_baseline legs")
     ap.add_argument("--cpu-sample-batch", type=int, default=4)
@@ -183,6 +206,11 @@ def main():
     ap.add_argument("--miopen", action="store_true",
                     help="let PyTorch use MIOpen for conv/BN (first use JIT-compiles per shape: minutes)")
     args = ap.parse_args()
+    global CONFIG
+    CONFIG = args.config
+    spec = configs.SPECS[CONFIG]
+    args.batch = spec["batch"] if args.batch is None else args.batch
+    args.points = spec["points"] if args.points is None else args.points
     # 1x1 convs and BatchNorm go through rocBLAS / native kernels; MIOpen would JIT-compile one
     # kernel per new shape on a fresh box, which swamps any short run.
     torch.backends.cudnn.enabled = bool(args.miopen)
@@ -207,16 +235,14 @@ def main():
     np.random.seed(1234 + rank)
     models = build(device, capturable=not args.no_graph)
     sync.broadcast_state(*models[:3])
-    clips = [fluid_clip(args.batch, args.points, 8, 3, seed=1234 + rank * 1000 + s, device=device)
+    clips = [configs.make_clip(CONFIG, batch=args.batch, points=args.points, seed=1234 + rank * 1000 + s, device=device)
              for s in range(4)]
     global GRAPHED, EAGER_BODY
     EAGER_BODY = bool(args.eager_body)
     mode = "eager"
     if not args.no_graph:
         try:
-            from tpgan_amd.gan_step_graph import GraphedFluidStep
-            G, Ds, Dt, opts = models
-            GRAPHED = GraphedFluidStep(G, Ds, Dt, opts, OPT, clips[0][0], clips[0][1], 1.0, amp_dtype, sync)
+            GRAPHED = configs.graphed_step(CONFIG, models, clips[0], amp_dtype=amp_dtype, sync=sync)
             mode = "hipgraph (%d graph%s per step)" % (len(GRAPHED._graphs[True]), "s" if len(GRAPHED._graphs[True]) > 1 else "")
         except Exception as e:   # noqa: BLE001 -- never lose the measurement to a capture problem
             GRAPHED = None
@@ -251,23 +277,24 @@ def main():
     log(f"timed region: {args.steps} steps in {dt:.3f} s")
 
     line = {
-        "metric": "GAN train-steps/sec (G+D) on 4096-pt x3-frame clips",
+        "metric": "GAN train-steps/sec (G+D) on %d-pt x%d-frame clips" % (args.points, spec["frames"]),
         "value": world * args.steps / dt, "unit": "steps/s", "n_gpus": world, "steps": args.steps,
         "warmup": args.warmup, "ms_per_step": 1e3 * dt / args.steps, "higher_is_better": True,
         "scaling": "weak", "vs_baseline": None, "dtype": args.dtype if args.dtype == "fp32" else "bf16",
         "data": "synthetic",
-        "config": {"workload": f"cfg2: {args.points}-pt x3-frame fluid clips, batch {args.batch} per GPU, "
-                               "full G+D adversarial step (SRNet(3,128) + FluidTempoDis(3) + "
-                               "FluidSpatialDis, Adam), all-keep mask regime, gate open, even iteration",
+        "config": {"workload": spec["label"] + f"; batch {args.batch} per GPU",
                    "per_gpu_batch": args.batch, "global_batch": args.batch * world,
                    "value_definition": "batch-of-%d steps per second summed over ranks" % args.batch,
                    "precision": "bf16 autocast on 1x1 convs/linears; coordinates, neighbour search, "
                                 "indices, Chamfer in fp32" if args.dtype == "bf16" else "fp32",
+                   "parity": "indices bit-exact vs oracle; fp32 model outputs vs reference goldens 1e-5 (CPU) / 2e-4 "
+                             "(GPU: GEMM summation order through ~20 layers); the bf16 replayed step vs the fp32 eager "
+                             "step: tests/test_graph_gpu.py::test_bf16_graph_against_fp32_eager_at_bench_size",
                    "parallelism": f"dp{world}", "step_mode": mode, "last_losses": last},
     }
     if rank == 0 and world == 1 and not args.no_extra:
-        roof, table = roofline_leg(models, clips, min(args.steps, 5), sync, amp_dtype)
-        line["roofline"] = roof
+        extra, table = roofline_leg(models, clips, min(args.steps, 5), sync, amp_dtype)
+        line.update(extra)
         line["kernels"] = table
         log("roofline leg done, timing the CPU baseline")
         line["cpu_baseline"] = cpu_baseline(args.cpu_sample_batch, args.batch, args.points)

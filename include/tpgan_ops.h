@@ -221,7 +221,11 @@ int tpg_mlp_fwd(const void *x, long long P, int Cin, int Cout, int nseg, const f
  *     dx_out = a*gg + e - f*x_out      (a, bz, e, f per channel: tpg_mlp_consts, cb (nseg,4,Cout))
  * and is never stored: it is rebuilt in the MFMA operand prologue of both gradient kernels.
  *   mode 0 DENSE: gg = g_out (P,Cout) bf16, the activated gradient written by the next layer's dgrad
- *   mode 1 MAX  : g_out (P/K,Cout) bf16 = gradient of the max output, arg = its arg-max bytes
+ *   mode 1 MAX  : g_out (P/K,Cout) bf16 = a * lrelu'(y) * (gradient of the max output), one value per
+ *                 (group, channel), made by tpg_mlp_max_prep from that gradient and the forward's output y;
+ *                 arg = the arg-max bytes: the value belongs to row arg of its group, the others get 0
+ * The MFMA operand the kernels build is d = dx_out - e (one fma per element); e enters as a rank-one
+ * term (e^T W per input channel in tpg_mlp_dgrad's epilogue, e (x) sum_rows a_in in tpg_mlp_wgrad).
  * tpg_mlp_dgrad: g_in (P,Cin) bf16 = (dx_out . W) * lrelu'(z_in) and BN_in's backward sums:
  *   c12_in (nseg,2,Cin), dgamma_in / dbeta_in (Cin, summed over segments, may be NULL).
  *   ci_in (nseg,4,Cin) = sc | sh | mu | rs of BN_in (tpg_mlp_consts).  ws: tpg_mlp_workspace_bytes.
@@ -231,13 +235,15 @@ int tpg_mlp_fwd(const void *x, long long P, int Cin, int Cout, int nseg, const f
  * tpg_mlp_bn_bwd_apply: dx = a*(g - c1 - xhat*c2) for the tail's first BatchNorm (g already activated). */
 int tpg_mlp_consts(const float *mean, const float *rstd, const float *gamma, const float *beta, const float *c12,
                    int C, int nseg, float *ci, float *cb, void *stream);
+int tpg_mlp_max_prep(const void *gout, const void *y, const float *cb_out, float slope_out, long long rows, int C,
+                     int nseg, void *ag, void *stream);
 int tpg_mlp_dgrad(const void *x_out, const void *g_out, const uint8_t *arg, int K, const float *cb_out,
-                  float slope_out, const void *x_in, const float *ci_in, float slope_in, const float *W,
+                  const void *x_in, const float *ci_in, float slope_in, const float *W,
                   int w_per_seg, long long P, int Cin, int Cout, int nseg, int mode, void *g_in, float *c12_in,
                   float *dgamma_in, float *dbeta_in, void *ws, void *stream);
 size_t tpg_mlp_wgrad_workspace_bytes(long long P, int Cin, int Cout, int nseg);
 int tpg_mlp_wgrad(const void *x_out, const void *g_out, const uint8_t *arg, int K, const float *cb_out,
-                  float slope_out, const void *x_in, const float *ci_in, float slope_in, long long P, int Cin,
+                  const void *x_in, const float *ci_in, float slope_in, long long P, int Cin,
                   int Cout, int nseg, int mode, float *dW, void *ws, void *stream);
 int tpg_mlp_bn_bwd_apply(const void *g, const void *x, const float *ci, const float *c12, long long P, int C,
                          int nseg, void *dx, void *stream);

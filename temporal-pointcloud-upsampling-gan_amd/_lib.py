@@ -45,8 +45,9 @@ SIGNATURES = {
     "tpg_rowbn_bwd_sums": [_P, _I, _P, _I, _P, _P, _I, _L, _I, _I, _I, _P, _P, _P, _P, _F, _P, _P, _P, _P, _I, _P],
     "tpg_mlp_scale_shift": [_P, _P, _P, _P, _I, _I, _P, _P],
     "tpg_mlp_consts": [_P, _P, _P, _P, _P, _I, _I, _P, _P, _P],
-    "tpg_mlp_dgrad": [_P, _P, _P, _I, _P, _F, _P, _P, _F, _P, _I, _L, _I, _I, _I, _I, _P, _P, _P, _P, _P, _P],
-    "tpg_mlp_wgrad": [_P, _P, _P, _I, _P, _F, _P, _P, _F, _L, _I, _I, _I, _I, _P, _P, _P],
+    "tpg_mlp_max_prep": [_P, _P, _P, _F, _L, _I, _I, _P, _P],
+    "tpg_mlp_dgrad": [_P, _P, _P, _I, _P, _P, _P, _F, _P, _I, _L, _I, _I, _I, _I, _P, _P, _P, _P, _P, _P],
+    "tpg_mlp_wgrad": [_P, _P, _P, _I, _P, _P, _P, _F, _L, _I, _I, _I, _I, _P, _P, _P],
     "tpg_mlp_bn_bwd_apply": [_P, _P, _P, _P, _L, _I, _I, _P, _P],
     "tpg_mlp_fwd": [_P, _L, _I, _I, _I, _P, _F, _P, _I, _P, _F, _F, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P],
 }

@@ -143,8 +143,8 @@ __global__ __launch_bounds__(ML_THREADS, 2) void mlp_fwd_kernel(
                 for (int i = 0; i < 4; ++i) {
                     float a = __builtin_fmaf(bf16_lo(w[i]), sc[2 * i], sh[2 * i]);
                     float b = __builtin_fmaf(bf16_hi(w[i]), sc[2 * i + 1], sh[2 * i + 1]);
-                    a = a > 0.0f ? a : a * slope;
-                    b = b > 0.0f ? b : b * slope;
+                    a = fmaxf(a, a * slope);            // LeakyReLU for 0 <= slope <= 1
+                    b = fmaxf(b, b * slope);
                     cv.u[i] = pack_bf16x2(a, b);
                 }
                 afrag[st] = cv.v;
@@ -339,18 +339,24 @@ __global__ void mlp_scale_shift_kernel(const float *__restrict__ mean, const flo
 //
 // gg = the gradient arriving at BN_out's output, already multiplied by lrelu'(z):
 //   MODE_DENSE  g_out (P,COUT) bf16, produced by the NEXT layer's dgrad epilogue;
-//   MODE_MAX    the last layer: g (P/K,COUT) lives on each group's arg-max row only, and the sign of
-//               z = a*x_out + bz (bz = beta - mu*a) is taken here.
-// So dx_out is never stored: it is the A operand of the data-gradient MFMA (mlp_dgrad_kernel) and,
-// recomputed from the same rows, one operand of the weight-gradient MFMA (mlp_wgrad_kernel).
+//   MODE_MAX    the last layer: a*gg lives on each group's arg-max row only; g_out (P/K,COUT) bf16 holds
+//               it per (group, channel) (mlp_max_prep_kernel: a * lrelu'(y) * gout from the forward's
+//               output y), arg the row it belongs to.
+// dx_out is never stored.  The MFMA operand the kernels build is  d = dx_out - e  (one fma per
+// element, plus a compare / select for the arg-max row); the constant e enters as a rank-one term:
+// e^T W per input channel in the data gradient's epilogue, e (x) sum_rows(a_in) in the weight gradient.
 enum { MODE_DENSE = 0, MODE_MAX = 1 };
 
-// 8 consecutive channels of dx_out of one row -> 4 packed bf16 pairs.  cb = (a | bz | e | f) of the
-// 8 channels; k = the row's position inside its group (MODE_MAX)
+__device__ __forceinline__ void ld8(const float *p, float (&v)[8]) {
+    const float4 a = *reinterpret_cast<const float4 *>(p), b = *reinterpret_cast<const float4 *>(p + 4);
+    v[0] = a.x; v[1] = a.y; v[2] = a.z; v[3] = a.w; v[4] = b.x; v[5] = b.y; v[6] = b.z; v[7] = b.w;
+}
+
+// 8 consecutive channels of d = dx_out - e of one row -> 4 packed bf16 pairs.
+//   DENSE: d = a*g - f*x          MAX: d = (arg == k ? ag : 0) - f*x     (gr = g resp. ag = a*gg)
 template <int MODE>
-__device__ __forceinline__ void dx_out8(const uint4 xr, const uint4 gr, const uint2 ar, int k, const float (&a)[8],
-                                        const float (&bz)[8], const float (&e)[8], const float (&f)[8],
-                                        float slope, bool valid, unsigned (&o)[4]) {
+__device__ __forceinline__ void d_out8(const uint4 xr, const uint4 gr, const uint2 ar, int k, const float (&a)[8],
+                                       const float (&f)[8], unsigned (&o)[4]) {
     const unsigned xw[4] = {xr.x, xr.y, xr.z, xr.w}, gw[4] = {gr.x, gr.y, gr.z, gr.w};
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
@@ -359,34 +365,54 @@ __device__ __forceinline__ void dx_out8(const uint4 xr, const uint4 gr, const ui
         for (int h = 0; h < 2; ++h) {
             const int j = 2 * i + h;
             const float x = h ? bf16_hi(xw[i]) : bf16_lo(xw[i]);
-            float g = h ? bf16_hi(gw[i]) : bf16_lo(gw[i]);
+            const float g = h ? bf16_hi(gw[i]) : bf16_lo(gw[i]);
             if (MODE == MODE_MAX) {
-                const int ak = (int)(((j < 4 ? ar.x : ar.y) >> (8 * (j & 3))) & 0xffu);
-                const float z = __builtin_fmaf(x, a[j], bz[j]);
-                g = z > 0.0f ? g : g * slope;
-                g = ak == k ? g : 0.0f;
+                const int ak = (int)__builtin_amdgcn_ubfe(j < 4 ? ar.x : ar.y, 8 * (j & 3), 8);
+                v[h] = __builtin_fmaf(-f[j], x, ak == k ? g : 0.0f);
+            } else {
+                v[h] = __builtin_fmaf(a[j], g, -f[j] * x);
             }
-            float t = __builtin_fmaf(-f[j], x, e[j]);
-            t = __builtin_fmaf(a[j], g, t);
-            v[h] = valid ? t : 0.0f;
         }
         o[i] = pack_bf16x2(v[0], v[1]);
     }
 }
 
-__device__ __forceinline__ void ld8(const float *p, float (&v)[8]) {
-    const float4 a = *reinterpret_cast<const float4 *>(p), b = *reinterpret_cast<const float4 *>(p + 4);
-    v[0] = a.x; v[1] = a.y; v[2] = a.z; v[3] = a.w; v[4] = b.x; v[5] = b.y; v[6] = b.z; v[7] = b.w;
+// MODE_MAX preparation: ag (rows,C) bf16 = a * (y > 0 ? g : slope*g) per (group, channel); grid.y = segment.
+// (lrelu keeps the sign, so the forward's OUTPUT y of the arg-max row tells which branch it took;
+// slope == 0: y == 0 there and the gradient is 0 either way.)
+__global__ void mlp_max_prep_kernel(const __hip_bfloat16 *__restrict__ g, const __hip_bfloat16 *__restrict__ y,
+                                    const float *__restrict__ cb, float slope, long long rows, int C,
+                                    __hip_bfloat16 *__restrict__ ag) {
+    const int seg = blockIdx.y;
+    const long long n8 = rows * C / 8;
+    const float *a = cb + (size_t)seg * 4 * C;
+    for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n8; i += (long long)gridDim.x * blockDim.x) {
+        const size_t off = (size_t)seg * rows * C + (size_t)i * 8;
+        const int c = (int)((i * 8) % C);
+        const uint4 gv = *reinterpret_cast<const uint4 *>(g + off), yv = *reinterpret_cast<const uint4 *>(y + off);
+        const unsigned gw[4] = {gv.x, gv.y, gv.z, gv.w}, yw[4] = {yv.x, yv.y, yv.z, yv.w};
+        float av[8];
+        ld8(a + c, av);
+        unsigned o[4];
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            const float g0 = bf16_lo(gw[q]), g1 = bf16_hi(gw[q]);
+            const float v0 = av[2 * q] * (bf16_lo(yw[q]) > 0.0f ? g0 : g0 * slope);
+            const float v1 = av[2 * q + 1] * (bf16_hi(yw[q]) > 0.0f ? g1 : g1 * slope);
+            o[q] = pack_bf16x2(v0, v1);
+        }
+        *reinterpret_cast<uint4 *>(ag + off) = make_uint4(o[0], o[1], o[2], o[3]);
+    }
 }
 
-// data gradient: g_in = (dx_out . W) * lrelu'(z_in), rounded to bf16 and stored, plus the partial
-// sums of BN_in's backward (sum g_in | sum g_in * xhat_in, of the rounded values).
+// data gradient: g_in = ((dx_out) . W) * lrelu'(z_in), rounded to bf16 and stored, plus the partial
+// sums of BN_in's backward (sum g_in | sum g_in * (x_in - mu); the finalize multiplies by rstd).
 // grid (G, nseg).  cbo (nseg,4,COUT) = a|bz|e|f of BN_out; cbi (nseg,4,CIN) = sc|sh|mu|rs of BN_in.
 // part (nseg, G, 2, CIN).
 template <int CIN, int COUT, int MODE, int STRIPS, int OCC>
 __global__ __launch_bounds__(ML_THREADS, OCC) void mlp_dgrad_kernel(
     const __hip_bfloat16 *__restrict__ x_out, const __hip_bfloat16 *__restrict__ g_out,
-    const uint8_t *__restrict__ arg, int K, const float *__restrict__ cbo, float slope_out,
+    const uint8_t *__restrict__ arg, int K, const float *__restrict__ cbo,
     const __hip_bfloat16 *__restrict__ x_in, const float *__restrict__ cbi, float slope_in,
     const float *__restrict__ W, int w_per_seg, long long P, __hip_bfloat16 *__restrict__ g_in,
     float *__restrict__ part) {
@@ -396,8 +422,9 @@ __global__ __launch_bounds__(ML_THREADS, OCC) void mlp_dgrad_kernel(
     constexpr int WROW = COUT + ML_WPAD;
     extern __shared__ __attribute__((aligned(16))) unsigned char ml_smem[];
     unsigned short *wl = reinterpret_cast<unsigned short *>(ml_smem);                  // [CIN][WROW]: W^T
-    float *cst = reinterpret_cast<float *>(ml_smem + (size_t)CIN * WROW * 2);          // [4][COUT]
-    float *red = cst + 4 * COUT;                                                       // [ML_WAVES][2][CIN]
+    float *cst = reinterpret_cast<float *>(ml_smem + (size_t)CIN * WROW * 2);          // a[COUT] | f[COUT] | e[COUT]
+    float *bias = cst + 3 * COUT;                                                      // [CIN]: e^T W
+    float *red = bias + CIN;                                                           // [ML_WAVES][2][CIN]
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int li = lane & 15, lq = lane >> 4;
     const int seg = blockIdx.y;
@@ -419,18 +446,31 @@ __global__ __launch_bounds__(ML_THREADS, OCC) void mlp_dgrad_kernel(
                 wl[(size_t)w_lds_row<CIN>(k + i) * WROW + n] = *reinterpret_cast<const unsigned short *>(&b);
             }
         }
-        for (int c = tid; c < 4 * COUT; c += ML_THREADS) cst[c] = cbo[(size_t)seg * 4 * COUT + c];
+        const float *cb = cbo + (size_t)seg * 4 * COUT;
+        for (int c = tid; c < COUT; c += ML_THREADS) {
+            cst[c] = cb[c];                       // a
+            cst[COUT + c] = cb[3 * COUT + c];     // f
+            cst[2 * COUT + c] = cb[2 * COUT + c]; // e
+        }
+    }
+    __syncthreads();
+    // rank-one part of the product: bias[ci] = sum_co e[co] * W[co][ci] (the bf16 weight the MFMA uses)
+    for (int ci = tid; ci < CIN; ci += ML_THREADS) {
+        const unsigned short *wr = wl + (size_t)w_lds_row<CIN>(ci) * WROW;
+        float acc = 0.0f;
+        for (int co = 0; co < COUT; ++co) acc = __builtin_fmaf(cst[2 * COUT + co], __uint_as_float((unsigned)wr[co] << 16), acc);
+        bias[ci] = acc;
     }
     __syncthreads();
     // BN_in constants of the lane's TI input channels li*TI + t
-    float sc[TI], sh[TI], mu[TI], rs[TI], sg[TI], sgx[TI];
+    float sc[TI], sh[TI], mu[TI], bi[TI], sg[TI], sgx[TI];
 #pragma unroll
     for (int t = 0; t < TI; ++t) {
         const int c = li * TI + t;
         sc[t] = cbi[((size_t)seg * 4 + 0) * CIN + c];
         sh[t] = cbi[((size_t)seg * 4 + 1) * CIN + c];
         mu[t] = cbi[((size_t)seg * 4 + 2) * CIN + c];
-        rs[t] = cbi[((size_t)seg * 4 + 3) * CIN + c];
+        bi[t] = bias[c];
         sg[t] = 0.0f;
         sgx[t] = 0.0f;
     }
@@ -438,9 +478,26 @@ __global__ __launch_bounds__(ML_THREADS, OCC) void mlp_dgrad_kernel(
     const unsigned short *wfrag = wl + (size_t)li * WROW + 8 * lq;    // + t*16*WROW + 32*s
     uint4 xraw[STRIPS][KS], graw[STRIPS][KS];
     uint2 araw[STRIPS][KS];
+    unsigned xin[STRIPS][4][TI / 2];          // x_in at the accumulator positions (rows 4*lq + r, channels li*TI ..)
     auto load_tile = [&](long long tile) {
 #pragma unroll
         for (int st = 0; st < STRIPS; ++st) {
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                long long rr = tile * BM + (wave * STRIPS + st) * 16 + 4 * lq + r;
+                rr = rr < P ? rr : P - 1;
+                const __hip_bfloat16 *pi = x_in + (size_t)rr * CIN + li * TI;
+                if constexpr (TI == 4) {
+                    const uint2 v = *reinterpret_cast<const uint2 *>(pi);
+                    xin[st][r][0] = v.x; xin[st][r][1] = v.y;
+                } else {
+#pragma unroll
+                    for (int v4 = 0; v4 < TI / 8; ++v4) {
+                        const uint4 v = reinterpret_cast<const uint4 *>(pi)[v4];
+                        xin[st][r][4 * v4] = v.x; xin[st][r][4 * v4 + 1] = v.y; xin[st][r][4 * v4 + 2] = v.z; xin[st][r][4 * v4 + 3] = v.w;
+                    }
+                }
+            }
             long long row = tile * BM + (wave * STRIPS + st) * 16 + li;
             row = row < P ? row : P - 1;
             const __hip_bfloat16 *px = x_out + (size_t)row * COUT + 8 * lq;
@@ -468,18 +525,17 @@ __global__ __launch_bounds__(ML_THREADS, OCC) void mlp_dgrad_kernel(
             for (int t = 0; t < TI; ++t) acc[st][t] = f32x4{0.0f, 0.0f, 0.0f, 0.0f};
 #pragma unroll
         for (int s = 0; s < KS; ++s) {
-            float ca[8], cbz[8], ce[8], cf[8];
-            ld8(cst + 0 * COUT + 32 * s + 8 * lq, ca);
-            ld8(cst + 1 * COUT + 32 * s + 8 * lq, cbz);
-            ld8(cst + 2 * COUT + 32 * s + 8 * lq, ce);
-            ld8(cst + 3 * COUT + 32 * s + 8 * lq, cf);
+            float ca[8], cf[8];
+            if (MODE == MODE_DENSE) ld8(cst + 32 * s + 8 * lq, ca);
+            ld8(cst + COUT + 32 * s + 8 * lq, cf);
             bf16x8 afrag[STRIPS];
 #pragma unroll
             for (int st = 0; st < STRIPS; ++st) {
                 const long long row = row_base + st * 16 + li;
                 union { unsigned u[4]; bf16x8 v; } cv;
-                dx_out8<MODE>(xraw[st][s], graw[st][s], araw[st][s], MODE == MODE_MAX ? (int)((unsigned)row % (unsigned)K) : 0, ca, cbz, ce, cf,
-                              slope_out, row < P, cv.u);
+                d_out8<MODE>(xraw[st][s], graw[st][s], araw[st][s], MODE == MODE_MAX ? (int)((unsigned)row % (unsigned)K) : 0, ca,
+                             cf, cv.u);
+                if (row >= P) { cv.u[0] = 0u; cv.u[1] = 0u; cv.u[2] = 0u; cv.u[3] = 0u; }
                 afrag[st] = cv.v;
             }
 #pragma unroll
@@ -491,43 +547,26 @@ __global__ __launch_bounds__(ML_THREADS, OCC) void mlp_dgrad_kernel(
                 if ((t & 3) == 3) __builtin_amdgcn_sched_barrier(0);
             }
         }
-        if (tile + gridDim.x < ntiles) load_tile(tile + gridDim.x);
-        // ---- epilogue: the activation's derivative from x_in, BN_in's sums, the bf16 rows of g_in
+        // ---- epilogue: + e^T W, the activation's derivative from x_in, BN_in's sums, the bf16 rows of g_in
 #pragma unroll
         for (int st = 0; st < STRIPS; ++st)
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
                 const long long row = row_base + st * 16 + 4 * lq + r;
                 const bool valid = row < P;
-                const long long rr = valid ? row : P - 1;
-                unsigned xin[TI / 2];
-                {
-                    const __hip_bfloat16 *px = x_in + (size_t)rr * CIN + li * TI;
-                    if constexpr (TI == 4) {
-                        const uint2 v = *reinterpret_cast<const uint2 *>(px);
-                        xin[0] = v.x; xin[1] = v.y;
-                    } else {
-#pragma unroll
-                        for (int v4 = 0; v4 < TI / 8; ++v4) {
-                            const uint4 v = reinterpret_cast<const uint4 *>(px)[v4];
-                            xin[4 * v4] = v.x; xin[4 * v4 + 1] = v.y; xin[4 * v4 + 2] = v.z; xin[4 * v4 + 3] = v.w;
-                        }
-                    }
-                }
+                const float vm = valid ? 1.0f : 0.0f;        // (rows past P: their d was zeroed, the bias is not)
                 unsigned o[TI / 2];
 #pragma unroll
                 for (int t = 0; t < TI; t += 2) {
-                    const float x0 = bf16_lo(xin[t / 2]), x1 = bf16_hi(xin[t / 2]);
+                    const float x0 = bf16_lo(xin[st][r][t / 2]), x1 = bf16_hi(xin[st][r][t / 2]);
                     const float z0 = __builtin_fmaf(x0, sc[t], sh[t]), z1 = __builtin_fmaf(x1, sc[t + 1], sh[t + 1]);
-                    const float g0 = z0 > 0.0f ? acc[st][t][r] : acc[st][t][r] * slope_in;
-                    const float g1 = z1 > 0.0f ? acc[st][t + 1][r] : acc[st][t + 1][r] * slope_in;
-                    const unsigned w = pack_bf16x2(g0, g1);
-                    o[t / 2] = w;
-                    const float q0 = valid ? bf16_lo(w) : 0.0f, q1 = valid ? bf16_hi(w) : 0.0f;
-                    sg[t] += q0;
-                    sg[t + 1] += q1;
-                    sgx[t] = __builtin_fmaf(q0, (x0 - mu[t]) * rs[t], sgx[t]);
-                    sgx[t + 1] = __builtin_fmaf(q1, (x1 - mu[t + 1]) * rs[t + 1], sgx[t + 1]);
+                    const float g0 = (acc[st][t][r] + bi[t]) * (z0 > 0.0f ? vm : vm * slope_in);
+                    const float g1 = (acc[st][t + 1][r] + bi[t + 1]) * (z1 > 0.0f ? vm : vm * slope_in);
+                    o[t / 2] = pack_bf16x2(g0, g1);
+                    sg[t] += g0;
+                    sg[t + 1] += g1;
+                    sgx[t] = __builtin_fmaf(g0, x0 - mu[t], sgx[t]);
+                    sgx[t + 1] = __builtin_fmaf(g1, x1 - mu[t + 1], sgx[t + 1]);
                 }
                 if (valid) {
                     __hip_bfloat16 *pg = g_in + (size_t)row * CIN + li * TI;
@@ -537,6 +576,8 @@ __global__ __launch_bounds__(ML_THREADS, OCC) void mlp_dgrad_kernel(
                     if constexpr (TI == 4) *reinterpret_cast<uint2 *>(pg) = make_uint2(o[0], o[1]);
                 }
             }
+        // the next tile's operands travel while the other waves of the CU compute
+        if (tile + gridDim.x < ntiles) load_tile(tile + gridDim.x);
     }
     // ---- per-wave sums -> per-workgroup partials (fixed order)
 #pragma unroll
@@ -563,10 +604,12 @@ __global__ __launch_bounds__(ML_THREADS, OCC) void mlp_dgrad_kernel(
     }
 }
 
-// partial sums of the data-gradient kernel -> c12 (nseg,2,C) = (sum g / P | sum g xhat / P) per segment,
-// dgamma = sum over segments of sum g xhat, dbeta = of sum g (both optional); grid ceil(C/4)
+// partial sums of the data-gradient kernel (sum g | sum g (x - mu)) -> c12 (nseg,2,C) = (sum g / P |
+// rstd * sum g (x - mu) / P) per segment, dgamma = sum over segments of sum g xhat, dbeta = of sum g
+// (both optional); rstd of segment s at rstd + s*rstd_stride; grid ceil(C/4)
 __global__ __launch_bounds__(ML_THREADS) void mlp_bwd_finalize_kernel(const float *__restrict__ part, int G, long long P,
-                                                                      int C, int nseg, float *__restrict__ c12,
+                                                                      int C, int nseg, const float *__restrict__ rstd,
+                                                                      int rstd_stride, float *__restrict__ c12,
                                                                       float *__restrict__ dgamma,
                                                                       float *__restrict__ dbeta) {
     __shared__ double red[2][MF_LANES][MF_CH];
@@ -592,7 +635,7 @@ __global__ __launch_bounds__(ML_THREADS) void mlp_bwd_finalize_kernel(const floa
             __syncthreads();
         }
         if (gl == 0 && c < C) {
-            const double s = red[0][0][cl], sx = red[1][0][cl];
+            const double s = red[0][0][cl], sx = red[1][0][cl] * (double)rstd[(size_t)seg * rstd_stride + c];
             ts += s;
             tsx += sx;
             c12[((size_t)seg * 2 + 0) * C + c] = (float)(s / (double)P);
@@ -630,9 +673,12 @@ __global__ void mlp_consts_kernel(const float *__restrict__ mean, const float *_
     }
 }
 
-// weight gradient: dW[co][ci] = sum_rows dx_out[row][co] * a_in[row][ci], both operands recomputed
-// from the saved bf16 rows (dx_out as above, a_in = lrelu(sc*x_in + sh)), staged row-major in LDS
-// tile by tile and read transposed (ds_read_b64_tr_b16) as MFMA operands with K = rows.
+// weight gradient: dW[co][ci] = sum_rows dx_out[row][co] * a_in[row][ci]
+//                             = sum_rows d[row][co] * a_in[row][ci]  +  e[co] * sum_rows a_in[row][ci]
+// with d = dx_out - e and a_in = lrelu(sc*x_in + sh) rebuilt from the saved bf16 rows, staged row-major
+// in LDS tile by tile and read transposed (ds_read_b64_tr_b16) as MFMA operands with K = rows.
+// A thread stages ONE fixed 8-channel chunk of d and one of a_in (its per-channel constants live in
+// registers); the next tile's rows are loaded into registers while the current tile is multiplied.
 // grid (G, nseg): a workgroup accumulates the whole (COUT x CIN) product of its row tiles in
 // registers (wave w owns output-channel tiles w*MT .. w*MT+MT-1) and writes one fp32 slab;
 // mlp_wgrad_reduce_kernel sums the G slabs in fixed order.
@@ -653,81 +699,101 @@ __device__ __forceinline__ bf16x8 tr_frag(const unsigned short *tile, int row_st
     return f;
 }
 
-template <int CIN, int COUT, int MODE>
-__global__ __launch_bounds__(ML_THREADS, 1) void mlp_wgrad_kernel(
+template <int CIN, int COUT, int MODE, int OCC>
+__global__ __launch_bounds__(ML_THREADS, OCC) void mlp_wgrad_kernel(
     const __hip_bfloat16 *__restrict__ x_out, const __hip_bfloat16 *__restrict__ g_out,
-    const uint8_t *__restrict__ arg, int K, const float *__restrict__ cbo, float slope_out,
+    const uint8_t *__restrict__ arg, int K, const float *__restrict__ cbo,
     const __hip_bfloat16 *__restrict__ x_in, const float *__restrict__ cbi, float slope_in, long long P,
     float *__restrict__ slab) {
     constexpr int MT = COUT / 16 / ML_WAVES;        // output-channel tiles per wave
     constexpr int NT = CIN / 16;
     constexpr int DROW = COUT + WG_PAD, AROW = CIN + WG_PAD;
-    static_assert(MT >= 1, "COUT >= 64");
+    constexpr int DCH = COUT / 8, ACH = CIN / 8;    // 16-byte chunks per row
+    constexpr int DN = WG_ROWS * DCH / ML_THREADS;  // chunks of d a thread stages per tile (same channels, rows DR apart)
+    constexpr int AN = WG_ROWS * ACH / ML_THREADS;
+    constexpr int DR = ML_THREADS / DCH, AR = ML_THREADS / ACH;
+    static_assert(MT >= 1 && DN >= 1 && AN >= 1, "tile shape");
     extern __shared__ __attribute__((aligned(16))) unsigned char ml_smem[];
     unsigned short *dxt = reinterpret_cast<unsigned short *>(ml_smem);                 // [WG_ROWS][DROW]
     unsigned short *at = dxt + (size_t)WG_ROWS * DROW;                                  // [WG_ROWS][AROW]
-    float *cst = reinterpret_cast<float *>(at + (size_t)WG_ROWS * AROW);                // [4][COUT] + [2][CIN]
+    float *ssum = reinterpret_cast<float *>(at + (size_t)WG_ROWS * AROW);               // [AR][CIN]
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const int li = lane & 15, lq = lane >> 4;
+    const int lq = lane >> 4, li = lane & 15;
     const int seg = blockIdx.y;
     x_out += (size_t)seg * P * COUT;
     x_in += (size_t)seg * P * CIN;
     if (MODE == MODE_DENSE) g_out += (size_t)seg * P * COUT;
     else { g_out += (size_t)seg * (P / K) * COUT; arg += (size_t)seg * (P / K) * COUT; }
-    for (int c = tid; c < 4 * COUT; c += ML_THREADS) cst[c] = cbo[(size_t)seg * 4 * COUT + c];
-    for (int c = tid; c < 2 * CIN; c += ML_THREADS) cst[4 * COUT + c] = cbi[(size_t)seg * 4 * CIN + c];
-    __syncthreads();
+    // this thread's chunks and their constants
+    const int dch = tid % DCH, drow = tid / DCH, ach = tid % ACH, arow = tid / ACH;
+    float ca[8], cf[8], sc[8], sh[8], asum[8];
+    ld8(cbo + ((size_t)seg * 4 + 0) * COUT + 8 * dch, ca);
+    ld8(cbo + ((size_t)seg * 4 + 3) * COUT + 8 * dch, cf);
+    ld8(cbi + ((size_t)seg * 4 + 0) * CIN + 8 * ach, sc);
+    ld8(cbi + ((size_t)seg * 4 + 1) * CIN + 8 * ach, sh);
+#pragma unroll
+    for (int i = 0; i < 8; ++i) asum[i] = 0.0f;
     f32x4 acc[MT][NT];
 #pragma unroll
     for (int m = 0; m < MT; ++m)
 #pragma unroll
         for (int n = 0; n < NT; ++n) acc[m][n] = f32x4{0.0f, 0.0f, 0.0f, 0.0f};
     const long long ntiles = (P + WG_ROWS - 1) / WG_ROWS;
-    constexpr int DCH = COUT / 8, ACH = CIN / 8;      // 16-byte chunks per row
-    for (long long tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
+    uint4 xr[DN], gr[DN], xi[AN];
+    uint2 ar[DN];
+    auto load_raw = [&](long long tile) {
         const long long r0 = tile * WG_ROWS;
-        // ---- stage dx_out (WG_ROWS x COUT) and a_in (WG_ROWS x CIN), coalesced 16-byte chunks
-        for (int e = tid; e < WG_ROWS * DCH; e += ML_THREADS) {
-            const int r = e / DCH, ch = e - r * DCH;
-            const long long row = r0 + r;
-            const bool valid = row < P;
-            const long long rr = valid ? row : P - 1;
+#pragma unroll
+        for (int i = 0; i < DN; ++i) {
+            long long rr = r0 + drow + i * DR;
+            rr = rr < P ? rr : P - 1;
             const long long grow = MODE == MODE_MAX ? (long long)((unsigned)rr / (unsigned)K) : rr;
-            const uint4 xr = *reinterpret_cast<const uint4 *>(x_out + (size_t)rr * COUT + 8 * ch);
-            const uint4 gr = *reinterpret_cast<const uint4 *>(g_out + (size_t)grow * COUT + 8 * ch);
-            uint2 ar = make_uint2(0u, 0u);
-            if (MODE == MODE_MAX) ar = *reinterpret_cast<const uint2 *>(arg + (size_t)grow * COUT + 8 * ch);
-            float ca[8], cbz[8], ce[8], cf[8];
-            ld8(cst + 0 * COUT + 8 * ch, ca);
-            ld8(cst + 1 * COUT + 8 * ch, cbz);
-            ld8(cst + 2 * COUT + 8 * ch, ce);
-            ld8(cst + 3 * COUT + 8 * ch, cf);
-            unsigned o[4];
-            dx_out8<MODE>(xr, gr, ar, MODE == MODE_MAX ? (int)((unsigned)rr % (unsigned)K) : 0, ca, cbz, ce, cf, slope_out, valid, o);
-            *reinterpret_cast<uint4 *>(dxt + (size_t)r * DROW + 8 * ch) = make_uint4(o[0], o[1], o[2], o[3]);
+            xr[i] = *reinterpret_cast<const uint4 *>(x_out + (size_t)rr * COUT + 8 * dch);
+            gr[i] = *reinterpret_cast<const uint4 *>(g_out + (size_t)grow * COUT + 8 * dch);
+            ar[i] = MODE == MODE_MAX ? *reinterpret_cast<const uint2 *>(arg + (size_t)grow * COUT + 8 * dch) : make_uint2(0u, 0u);
         }
-        for (int e = tid; e < WG_ROWS * ACH; e += ML_THREADS) {
-            const int r = e / ACH, ch = e - r * ACH;
+#pragma unroll
+        for (int i = 0; i < AN; ++i) {
+            long long rr = r0 + arow + i * AR;
+            rr = rr < P ? rr : P - 1;
+            xi[i] = *reinterpret_cast<const uint4 *>(x_in + (size_t)rr * CIN + 8 * ach);
+        }
+    };
+    long long tile = blockIdx.x;
+    if (tile < ntiles) load_raw(tile);
+    for (; tile < ntiles; tile += gridDim.x) {
+        const long long r0 = tile * WG_ROWS;
+        // ---- registers -> the two LDS tiles
+#pragma unroll
+        for (int i = 0; i < DN; ++i) {
+            const int r = drow + i * DR;
             const long long row = r0 + r;
-            const long long rr = row < P ? row : P - 1;
-            const uint4 xr = *reinterpret_cast<const uint4 *>(x_in + (size_t)rr * CIN + 8 * ch);
-            const unsigned xw[4] = {xr.x, xr.y, xr.z, xr.w};
-            float sc[8], sh[8];
-            ld8(cst + 4 * COUT + 8 * ch, sc);
-            ld8(cst + 4 * COUT + CIN + 8 * ch, sh);
+            unsigned o[4];
+            d_out8<MODE>(xr[i], gr[i], ar[i], MODE == MODE_MAX ? (int)((unsigned)(row < P ? row : P - 1) % (unsigned)K) : 0, ca, cf, o);
+            if (row >= P) { o[0] = 0u; o[1] = 0u; o[2] = 0u; o[3] = 0u; }
+            *reinterpret_cast<uint4 *>(dxt + (size_t)r * DROW + 8 * dch) = make_uint4(o[0], o[1], o[2], o[3]);
+        }
+#pragma unroll
+        for (int i = 0; i < AN; ++i) {
+            const int r = arow + i * AR;
+            const bool valid = r0 + r < P;
+            const unsigned xw[4] = {xi[i].x, xi[i].y, xi[i].z, xi[i].w};
             unsigned o[4];
 #pragma unroll
-            for (int i = 0; i < 4; ++i) {
-                float a = __builtin_fmaf(bf16_lo(xw[i]), sc[2 * i], sh[2 * i]);
-                float b = __builtin_fmaf(bf16_hi(xw[i]), sc[2 * i + 1], sh[2 * i + 1]);
-                a = a > 0.0f ? a : a * slope_in;
-                b = b > 0.0f ? b : b * slope_in;
-                o[i] = pack_bf16x2(a, b);          // (rows past P multiply a zero dx_out row)
+            for (int q = 0; q < 4; ++q) {
+                float a = __builtin_fmaf(bf16_lo(xw[q]), sc[2 * q], sh[2 * q]);
+                float b = __builtin_fmaf(bf16_hi(xw[q]), sc[2 * q + 1], sh[2 * q + 1]);
+                a = fmaxf(a, a * slope_in);
+                b = fmaxf(b, b * slope_in);
+                o[q] = valid ? pack_bf16x2(a, b) : 0u;
+                asum[2 * q] += bf16_lo(o[q]);          // of the rounded operand the MFMA sees
+                asum[2 * q + 1] += bf16_hi(o[q]);
             }
-            *reinterpret_cast<uint4 *>(at + (size_t)r * AROW + 8 * ch) = make_uint4(o[0], o[1], o[2], o[3]);
+            *reinterpret_cast<uint4 *>(at + (size_t)r * AROW + 8 * ach) = make_uint4(o[0], o[1], o[2], o[3]);
         }
         __syncthreads();
-        // ---- dW tiles: A' = dx_out^T (m = output channel, k = row), B' = a_in (k = row, n = input channel)
+        if (tile + gridDim.x < ntiles) load_raw(tile + gridDim.x);     // travels during the MFMA phase
+        // ---- dW tiles: A' = d^T (m = output channel, k = row), B' = a_in (k = row, n = input channel)
 #pragma unroll
         for (int ks = 0; ks < WG_ROWS / 32; ++ks) {
             bf16x8 af[MT];
@@ -744,29 +810,55 @@ __global__ __launch_bounds__(ML_THREADS, 1) void mlp_wgrad_kernel(
         }
         __syncthreads();                     // the tiles are restaged by the next iteration
     }
+    // ---- s[ci] = sum_rows a_in: the AR threads of a channel chunk, added in fixed order
+#pragma unroll
+    for (int i = 0; i < 8; ++i) ssum[(size_t)arow * CIN + 8 * ach + i] = asum[i];
+    __syncthreads();
+    float sv[NT];                            // s of the lane's columns 16*n + li
+#pragma unroll
+    for (int n = 0; n < NT; ++n) {
+        float t = 0.0f;
+        for (int r = 0; r < AR; ++r) t += ssum[(size_t)r * CIN + 16 * n + li];
+        sv[n] = t;
+    }
     // ---- slab (COUT, CIN) fp32: row = output channel 16*(wave*MT+m) + 4*lq + r, column = 16*n + li
     float *out = slab + ((size_t)seg * gridDim.x + blockIdx.x) * COUT * CIN;
+    const float *ce = cbo + ((size_t)seg * 4 + 2) * COUT;
 #pragma unroll
     for (int m = 0; m < MT; ++m)
 #pragma unroll
-        for (int n = 0; n < NT; ++n)
+        for (int r = 0; r < 4; ++r) {
+            const int co = 16 * (wave * MT + m) + 4 * lq + r;
+            const float e = ce[co];
 #pragma unroll
-            for (int r = 0; r < 4; ++r)
-                out[(size_t)(16 * (wave * MT + m) + 4 * lq + r) * CIN + 16 * n + li] = acc[m][n][r];
+            for (int n = 0; n < NT; ++n) out[(size_t)co * CIN + 16 * n + li] = __builtin_fmaf(e, sv[n], acc[m][n][r]);
+        }
 }
 
-// dW (nseg, COUT*CIN) = sum over the G slabs, in slab order
-__global__ void mlp_wgrad_reduce_kernel(const float *__restrict__ slab, int G, int n, float *__restrict__ dW) {
-    const int seg = blockIdx.y;
-    const int i = (blockIdx.x * blockDim.x + threadIdx.x) * 4;
-    if (i >= n) return;
-    const float *ps = slab + (size_t)seg * G * n + i;
+// dW (nseg, COUT*CIN) = sum over the G slabs: a block sums 64 float4 columns, its four 64-thread
+// groups take every fourth slab each and meet in LDS (fixed order: bitwise reproducible)
+__global__ __launch_bounds__(256) void mlp_wgrad_reduce_kernel(const float *__restrict__ slab, int G, int n,
+                                                                float *__restrict__ dW) {
+    __shared__ float4 part[4][64];
+    const int seg = blockIdx.y, col = threadIdx.x & 63, grp = threadIdx.x >> 6;
+    const int i = (blockIdx.x * 64 + col) * 4;
     float4 s = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
-    for (int g = 0; g < G; ++g) {
-        const float4 v = *reinterpret_cast<const float4 *>(ps + (size_t)g * n);
-        s.x += v.x; s.y += v.y; s.z += v.z; s.w += v.w;
+    if (i < n) {
+        const float *ps = slab + (size_t)seg * G * n + i;
+#pragma unroll 4
+        for (int g = grp; g < G; g += 4) {
+            const float4 v = *reinterpret_cast<const float4 *>(ps + (size_t)g * n);
+            s.x += v.x; s.y += v.y; s.z += v.z; s.w += v.w;
+        }
     }
-    *reinterpret_cast<float4 *>(dW + (size_t)seg * n + i) = s;
+    part[grp][col] = s;
+    __syncthreads();
+    if (grp == 0 && i < n) {
+        float4 t = part[0][col];
+#pragma unroll
+        for (int q = 1; q < 4; ++q) { t.x += part[q][col].x; t.y += part[q][col].y; t.z += part[q][col].z; t.w += part[q][col].w; }
+        *reinterpret_cast<float4 *>(dW + (size_t)seg * n + i) = t;
+    }
 }
 
 // dx = a * (g - c1 - xhat * c2): BatchNorm backward of the tail's FIRST BatchNorm, whose input came
@@ -874,10 +966,10 @@ int fwd_launch(const void *x, long long P, int nseg, const float *ss, float slop
 // half the LDS run alone on their CU and may use the whole register file
 template <int CIN, int COUT> constexpr int bwd_strips() { return (CIN == 64 && COUT <= 128) ? 2 : 1; }
 template <int CIN, int COUT> constexpr size_t dgrad_smem() {
-    return (size_t)CIN * (COUT + ML_WPAD) * 2 + sizeof(float) * (4 * COUT + ML_WAVES * 2 * CIN);
+    return (size_t)CIN * (COUT + ML_WPAD) * 2 + sizeof(float) * (3 * COUT + CIN + ML_WAVES * 2 * CIN);
 }
 template <int CIN, int COUT> constexpr size_t wgrad_smem() {
-    return (size_t)WG_ROWS * ((COUT + WG_PAD) + (CIN + WG_PAD)) * 2 + sizeof(float) * (4 * COUT + 2 * CIN);
+    return (size_t)WG_ROWS * ((COUT + WG_PAD) + (CIN + WG_PAD)) * 2 + sizeof(float) * (ML_THREADS / (CIN / 8)) * CIN;
 }
 
 template <typename Kern> bool raise_lds(Kern kern, size_t smem, bool *raised) {
@@ -890,20 +982,20 @@ template <typename Kern> bool raise_lds(Kern kern, size_t smem, bool *raised) {
 }
 
 template <int CIN, int COUT, int MODE>
-int dgrad_launch(const void *x_out, const void *g_out, const uint8_t *arg, int K, const float *cbo, float slope_out,
+int dgrad_launch(const void *x_out, const void *g_out, const uint8_t *arg, int K, const float *cbo,
                  const void *x_in, const float *cbi, float slope_in, const float *W, int w_per_seg, long long P, int nseg,
                  void *g_in, float *part, int *G_out, hipStream_t st) {
     constexpr int STRIPS = bwd_strips<CIN, COUT>();
     constexpr int BM = ML_WAVES * STRIPS * 16;
     constexpr size_t smem = dgrad_smem<CIN, COUT>();
-    constexpr int OCC = (smem > 80 * 1024 || CIN == 256) ? 1 : 2;
+    constexpr int OCC = (smem > 60 * 1024 || CIN == 256) ? 1 : 2;
     auto kern = mlp_dgrad_kernel<CIN, COUT, MODE, STRIPS, OCC>;
     static bool raised = false;
     if (!raise_lds(kern, smem, &raised)) return TPG_ERR_UNSUPPORTED;
     const int G = fwd_blocks(P, BM, nseg);
     *G_out = G;
     hipLaunchKernelGGL(kern, dim3(G, nseg), dim3(ML_THREADS), smem, st, static_cast<const __hip_bfloat16 *>(x_out),
-                       static_cast<const __hip_bfloat16 *>(g_out), arg, K, cbo, slope_out,
+                       static_cast<const __hip_bfloat16 *>(g_out), arg, K, cbo,
                        static_cast<const __hip_bfloat16 *>(x_in), cbi, slope_in, W, w_per_seg, P,
                        static_cast<__hip_bfloat16 *>(g_in), part);
     return TPG_OK;
@@ -914,22 +1006,24 @@ int dgrad_launch(const void *x_out, const void *g_out, const uint8_t *arg, int K
 int wgrad_blocks(long long P, int nseg, int Cin, int Cout) {
     const long long tiles = (P + WG_ROWS - 1) / WG_ROWS;
     const int d = nseg > 4 ? 4 : nseg;
-    long long g = P * (Cin + Cout) / (32LL * Cin * Cout);        // slab traffic <= 1/8 of the rows'
-    const long long lo = 128 / d, hi = 512 / d;
+    long long g = P * (Cin + Cout) / (8LL * Cin * Cout);         // slab traffic <= 1/2 of the rows'
+    const long long lo = 256 / d, hi = 768 / d;                  // ... but never fewer workgroups than CUs
     g = g < lo ? lo : (g > hi ? hi : g);
     return (int)(g < tiles ? g : tiles);
 }
 
 template <int CIN, int COUT, int MODE>
-int wgrad_launch(const void *x_out, const void *g_out, const uint8_t *arg, int K, const float *cbo, float slope_out,
+int wgrad_launch(const void *x_out, const void *g_out, const uint8_t *arg, int K, const float *cbo,
                  const void *x_in, const float *cbi, float slope_in, long long P, int nseg, float *slab, int G,
                  hipStream_t st) {
     constexpr size_t smem = wgrad_smem<CIN, COUT>();
-    auto kern = mlp_wgrad_kernel<CIN, COUT, MODE>;
+    // accumulators: COUT*CIN/256 registers per lane; from 128 of them on a workgroup has its SIMDs alone
+    constexpr int OCC = (COUT * CIN / ML_THREADS >= 128) ? 1 : 2;
+    auto kern = mlp_wgrad_kernel<CIN, COUT, MODE, OCC>;
     static bool raised = false;
     if (!raise_lds(kern, smem, &raised)) return TPG_ERR_UNSUPPORTED;
     hipLaunchKernelGGL(kern, dim3(G, nseg), dim3(ML_THREADS), smem, st, static_cast<const __hip_bfloat16 *>(x_out),
-                       static_cast<const __hip_bfloat16 *>(g_out), arg, K, cbo, slope_out,
+                       static_cast<const __hip_bfloat16 *>(g_out), arg, K, cbo,
                        static_cast<const __hip_bfloat16 *>(x_in), cbi, slope_in, P, slab);
     return TPG_OK;
 }
@@ -1002,8 +1096,25 @@ extern "C" int tpg_mlp_consts(const float *mean, const float *rstd, const float 
 
 #define TPG_ML_SHAPES(X) X(64, 64) X(64, 128) X(128, 64) X(128, 128) X(128, 256) X(256, 128) X(256, 256)
 
+extern "C" int tpg_mlp_max_prep(const void *gout, const void *y, const float *cb_out, float slope_out, long long rows,
+                                int C, int nseg, void *ag, void *stream) {
+    if (rows <= 0 || nseg < 1 || nseg > 65535 || rows % nseg || C <= 0 || C % 8 || !gout || !y || !cb_out || !ag)
+        return TPG_ERR_ARG;
+    if ((reinterpret_cast<uintptr_t>(gout) | reinterpret_cast<uintptr_t>(y) | reinterpret_cast<uintptr_t>(ag)) & 15)
+        return TPG_ERR_UNSUPPORTED;
+    rows /= nseg;
+    const long long n8 = rows * C / 8;
+    long long b = (n8 + 255) / 256;
+    b = b > 1024 ? 1024 : b;
+    hipLaunchKernelGGL(mlp_max_prep_kernel, dim3((unsigned)b, nseg), dim3(256), 0, tpg_stream(stream),
+                       static_cast<const __hip_bfloat16 *>(gout), static_cast<const __hip_bfloat16 *>(y), cb_out,
+                       slope_out, rows, C, static_cast<__hip_bfloat16 *>(ag));
+    TPG_RETURN_IF_LAUNCH_FAILED();
+    return TPG_OK;
+}
+
 extern "C" int tpg_mlp_dgrad(const void *x_out, const void *g_out, const uint8_t *arg, int K, const float *cb_out,
-                             float slope_out, const void *x_in, const float *ci_in, float slope_in, const float *W,
+                             const void *x_in, const float *ci_in, float slope_in, const float *W,
                              int w_per_seg, long long P, int Cin, int Cout, int nseg, int mode, void *g_in,
                              float *c12_in, float *dgamma_in, float *dbeta_in, void *ws, void *stream) {
     if (P <= 0 || nseg < 1 || nseg > 65535 || P % nseg || (mode != MODE_DENSE && mode != MODE_MAX)) return TPG_ERR_ARG;
@@ -1020,15 +1131,16 @@ extern "C" int tpg_mlp_dgrad(const void *x_out, const void *g_out, const uint8_t
     int G = 0, rc = TPG_ERR_UNSUPPORTED;
 #define TPG_ML_DG(CI, CO)                                                                                            \
     if (Cin == CI && Cout == CO)                                                                                     \
-        rc = mode == MODE_MAX ? dgrad_launch<CI, CO, MODE_MAX>(x_out, g_out, arg, K, cb_out, slope_out, x_in, ci_in,   \
+        rc = mode == MODE_MAX ? dgrad_launch<CI, CO, MODE_MAX>(x_out, g_out, arg, K, cb_out, x_in, ci_in,   \
                                                                slope_in, W, w_per_seg, P, nseg, g_in, part, &G, st)  \
-                              : dgrad_launch<CI, CO, MODE_DENSE>(x_out, g_out, arg, K, cb_out, slope_out, x_in, ci_in, \
+                              : dgrad_launch<CI, CO, MODE_DENSE>(x_out, g_out, arg, K, cb_out, x_in, ci_in, \
                                                                  slope_in, W, w_per_seg, P, nseg, g_in, part, &G, st);
     TPG_ML_SHAPES(TPG_ML_DG)
 #undef TPG_ML_DG
     if (rc) return rc;
+    // (ci_in = sc | sh | mu | rs per segment: the finalize reads rs with stride 4*Cin)
     hipLaunchKernelGGL(mlp_bwd_finalize_kernel, dim3((Cin + MF_CH - 1) / MF_CH), dim3(ML_THREADS), 0, st, part, G, P, Cin,
-                       nseg, c12_in, dgamma_in, dbeta_in);
+                       nseg, ci_in + 3 * Cin, 4 * Cin, c12_in, dgamma_in, dbeta_in);
     TPG_RETURN_IF_LAUNCH_FAILED();
     return TPG_OK;
 }
@@ -1040,7 +1152,7 @@ extern "C" size_t tpg_mlp_wgrad_workspace_bytes(long long P, int Cin, int Cout, 
 }
 
 extern "C" int tpg_mlp_wgrad(const void *x_out, const void *g_out, const uint8_t *arg, int K, const float *cb_out,
-                             float slope_out, const void *x_in, const float *ci_in, float slope_in, long long P, int Cin,
+                             const void *x_in, const float *ci_in, float slope_in, long long P, int Cin,
                              int Cout, int nseg, int mode, float *dW, void *ws, void *stream) {
     if (P <= 0 || nseg < 1 || nseg > 65535 || P % nseg || (mode != MODE_DENSE && mode != MODE_MAX)) return TPG_ERR_ARG;
     if (!x_out || !g_out || !cb_out || !x_in || !ci_in || !dW || !ws) return TPG_ERR_ARG;
@@ -1056,15 +1168,15 @@ extern "C" int tpg_mlp_wgrad(const void *x_out, const void *g_out, const uint8_t
     int rc = TPG_ERR_UNSUPPORTED;
 #define TPG_ML_WG(CI, CO)                                                                                           \
     if (Cin == CI && Cout == CO)                                                                                    \
-        rc = mode == MODE_MAX ? wgrad_launch<CI, CO, MODE_MAX>(x_out, g_out, arg, K, cb_out, slope_out, x_in, ci_in,  \
+        rc = mode == MODE_MAX ? wgrad_launch<CI, CO, MODE_MAX>(x_out, g_out, arg, K, cb_out, x_in, ci_in,  \
                                                                slope_in, P, nseg, slab, G, st)                      \
-                              : wgrad_launch<CI, CO, MODE_DENSE>(x_out, g_out, arg, K, cb_out, slope_out, x_in, ci_in, \
+                              : wgrad_launch<CI, CO, MODE_DENSE>(x_out, g_out, arg, K, cb_out, x_in, ci_in, \
                                                                  slope_in, P, nseg, slab, G, st);
     TPG_ML_SHAPES(TPG_ML_WG)
 #undef TPG_ML_WG
     if (rc) return rc;
     const int n = Cin * Cout;
-    hipLaunchKernelGGL(mlp_wgrad_reduce_kernel, dim3((n / 4 + 255) / 256, nseg), dim3(256), 0, st, slab, G, n, dW);
+    hipLaunchKernelGGL(mlp_wgrad_reduce_kernel, dim3((n / 4 + 63) / 64, nseg), dim3(256), 0, st, slab, G, n, dW);
     TPG_RETURN_IF_LAUNCH_FAILED();
     return TPG_OK;
 }

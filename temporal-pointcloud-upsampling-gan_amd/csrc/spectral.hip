@@ -131,18 +131,27 @@ __global__ __launch_bounds__(SN_THREADS) void spectral_norm_multi_fwd_kernel(con
         float *o = out + d.out_off + (size_t)t * sn_stride(R, Cn);
         float *ou = o + n, *ov = ou + R;
         if (iterate) {
-            // t = W^T u: wave w takes rows w, w+16, ...; lanes take columns; partial column sums
-            // are combined through LDS (sv) with one atomic add per (wave, column)
-            for (int j = tid; j < Cn; j += SN_THREADS) sv[j] = 0.0f;
-            __syncthreads();
+            // t = W^T u: wave w takes rows w, w+16, ...; lanes take columns; the 16 waves' partial
+            // column sums meet in an LDS slab and are added in WAVE ORDER by the first wave (a float
+            // atomic per (wave, column) summed in arrival order: u, v, sigma -- hence every weight of
+            // the step -- differed in the last bit from run to run, which the step then amplifies;
+            // tests/test_graph_gpu.py compares a replay with its own body bit for bit)
+            float *slab = scratch + 16;                     // [16 waves][64 columns]
             for (int j0 = 0; j0 < Cn; j0 += 64) {
                 const int j = j0 + lane;
                 float acc = 0.0f;
                 if (j < Cn)
                     for (int i = wave; i < R; i += SN_THREADS / 64) acc += W[(size_t)i * Cn + j] * su[i];
-                if (j < Cn) atomicAdd(&sv[j], acc);
+                slab[wave * 64 + lane] = acc;
+                __syncthreads();
+                if (wave == 0 && j < Cn) {
+                    float t = 0.0f;
+#pragma unroll
+                    for (int w = 0; w < SN_THREADS / 64; ++w) t += slab[w * 64 + lane];
+                    sv[j] = t;
+                }
+                __syncthreads();
             }
-            __syncthreads();
             float nrm = 0.0f;
             for (int j = tid; j < Cn; j += SN_THREADS) nrm += sv[j] * sv[j];
             nrm = block_sum(nrm, scratch);
@@ -259,7 +268,7 @@ extern "C" int tpg_spectral_norm_multi_fwd(const void *desc, int M, int max_rc, 
                                            void *stream) {
     if (M < 0 || !desc || !out) return TPG_ERR_ARG;
     if (M == 0) return TPG_OK;
-    const size_t smem = sizeof(float) * ((size_t)max_rc + 64);
+    const size_t smem = sizeof(float) * ((size_t)max_rc + 64 + 16 * 64);     // u | v | scratch | column slab
     if (smem > 48 * 1024) return TPG_ERR_UNSUPPORTED;
     hipLaunchKernelGGL(spectral_norm_multi_fwd_kernel, dim3(M), dim3(SN_THREADS), smem, tpg_stream(stream),
                        static_cast<const SnDesc *>(desc), out, iterate, eps);

@@ -169,25 +169,28 @@ class _TallLinear(torch.autograd.Function):
         ctx.save_for_backward(xd, wd)
         ctx.w_dtype, ctx.x_dtype = w.dtype, x.dtype
         ctx.b_dtype = None if bias is None else bias.dtype
+        P, cin, cout, e = xd.shape[0], xd.shape[1], wd.shape[0], xd.element_size()
         if bias is None:
-            return xd @ wd.t()
-        return torch.addmm(shadow_cast(bias, dtype), xd, wd.t())  # bias in the GEMM epilogue
+            return ops.timed("gemm_fwd", e * P * (cin + cout), 2 * P * cin * cout, xd, lambda: xd @ wd.t())
+        return ops.timed("gemm_fwd", e * P * (cin + cout), 2 * P * cin * cout, xd,
+                         lambda: torch.addmm(shadow_cast(bias, dtype), xd, wd.t()))  # bias in the GEMM epilogue
 
     @staticmethod
     def backward(ctx, gy):
         xd, wd = ctx.saved_tensors
         gy = gy.to(xd.dtype)
         dx = dw = db = None
+        P, cin, cout, e = xd.shape[0], xd.shape[1], wd.shape[0], xd.element_size()
         if ctx.needs_input_grad[0]:
-            dx = (gy @ wd).to(ctx.x_dtype)
+            dx = ops.timed("gemm_dgrad", e * P * (cin + cout), 2 * P * cin * cout, gy, lambda: gy @ wd).to(ctx.x_dtype)
         if ctx.needs_input_grad[1]:
-            P = xd.shape[0]
             S = _split_k(P, wd.shape[0], wd.shape[1])
             if S > 1:
                 rows = P // S
                 head = S * rows
-                dw = _mm_f32(torch.bmm, gy[:head].view(S, rows, -1).transpose(1, 2),
-                             xd[:head].view(S, rows, -1)).sum(0)
+                dw = ops.timed("gemm_wgrad", e * P * (cin + cout), 2 * P * cin * cout, gy,
+                               lambda: _mm_f32(torch.bmm, gy[:head].view(S, rows, -1).transpose(1, 2),
+                                               xd[:head].view(S, rows, -1))).sum(0)
                 if head < P:
                     dw = dw + _mm_f32(torch.mm, gy[head:].t(), xd[head:])
             else:
@@ -230,7 +233,8 @@ class _TallLinearSeg(torch.autograd.Function):
         wd = w.to(dtype)
         ctx.save_for_backward(xd, wd)
         ctx.w_dtype, ctx.x_dtype = w.dtype, x.dtype
-        return torch.bmm(xd, wd.transpose(1, 2)).view(nseg * P, cout)
+        return ops.timed("gemm_fwd", xd.element_size() * nseg * P * (cin + cout), 2 * nseg * P * cin * cout, xd,
+                         lambda: torch.bmm(xd, wd.transpose(1, 2))).view(nseg * P, cout)
 
     @staticmethod
     def backward(ctx, gy):
@@ -239,14 +243,17 @@ class _TallLinearSeg(torch.autograd.Function):
         cout = wd.shape[1]
         gy = gy.to(xd.dtype).view(nseg, P, cout)
         dx = dw = None
+        e = xd.element_size()
         if ctx.needs_input_grad[0]:
-            dx = torch.bmm(gy, wd).view(nseg * P, cin).to(ctx.x_dtype)
+            dx = ops.timed("gemm_dgrad", e * nseg * P * (cin + cout), 2 * nseg * P * cin * cout, gy,
+                           lambda: torch.bmm(gy, wd)).view(nseg * P, cin).to(ctx.x_dtype)
         if ctx.needs_input_grad[1]:
             S = _split_k(P, cout, cin)
             rows = P // S
             head = S * rows
-            part = _mm_f32(torch.bmm, gy[:, :head].reshape(nseg * S, rows, cout).transpose(1, 2),
-                           xd[:, :head].reshape(nseg * S, rows, cin))
+            part = ops.timed("gemm_wgrad", e * nseg * P * (cin + cout), 2 * nseg * P * cin * cout, gy,
+                             lambda: _mm_f32(torch.bmm, gy[:, :head].reshape(nseg * S, rows, cout).transpose(1, 2),
+                                             xd[:, :head].reshape(nseg * S, rows, cin)))
             dw = part.view(nseg, S, cout, cin).sum(1) if S > 1 else part.view(nseg, cout, cin)
             if head < P:
                 dw = dw + _mm_f32(torch.bmm, gy[:, head:].transpose(1, 2), xd[:, head:])

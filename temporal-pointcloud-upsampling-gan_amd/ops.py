@@ -25,26 +25,30 @@ class OpTimer:
     def __init__(self):
         self.pending = {}   # name -> [(start_evt, end_evt, algorithmic_bytes)]
 
-    def record(self, name, nbytes, stream_of, launch):
+    def record(self, name, nbytes, stream_of, launch, flops=0):
         st = torch.cuda.current_stream(stream_of.device)
         a = torch.cuda.Event(enable_timing=True)
         b = torch.cuda.Event(enable_timing=True)
         a.record(st)
         out = launch()
         b.record(st)
-        self.pending.setdefault(name, []).append((a, b, nbytes))
+        self.pending.setdefault(name, []).append((a, b, nbytes, flops))
         return out
 
     def summary(self):
-        """name -> dict(launches, total_ms, avg_us, bytes_per_launch, gbps); call after a sync."""
+        """name -> dict(launches, total_ms, avg_us, bytes_per_launch, gbps, flops_per_launch, tflops);
+        call after a sync."""
         out = {}
         for name, recs in self.pending.items():
-            ms = [a.elapsed_time(b) for a, b, _ in recs]
-            by = [n for _, _, n in recs]
+            ms = [a.elapsed_time(b) for a, b, _, _ in recs]
+            by = [n for _, _, n, _ in recs]
+            fl = [f for _, _, _, f in recs]
             tot = sum(ms)
             out[name] = dict(launches=len(recs), total_ms=tot, avg_us=1e3 * tot / len(recs),
                              bytes_per_launch=sum(by) / len(by),
-                             gbps=(sum(by) / 1e9) / (tot / 1e3) if tot > 0 else 0.0)
+                             gbps=(sum(by) / 1e9) / (tot / 1e3) if tot > 0 else 0.0,
+                             flops_per_launch=sum(fl) / len(fl),
+                             tflops=(sum(fl) / 1e12) / (tot / 1e3) if tot > 0 else 0.0)
         return out
 
 
@@ -58,10 +62,15 @@ def set_timer(timer):
     return prev
 
 
-def _run(name, nbytes, t, launch):
+def _run(name, nbytes, t, launch, flops=0):
     if _timer is None:
         return launch()
-    return _timer.record(name, nbytes, t, launch)
+    return _timer.record(name, nbytes, t, launch, flops)
+
+
+def timed(name, nbytes, flops, t, launch):
+    """Run `launch()` (a library GEMM of the host layer) under the per-kernel timer, if one is installed."""
+    return _run(name, nbytes, t, launch, flops)
 
 
 def register_backend(device_type, impl):
@@ -121,10 +130,10 @@ class HipBackend:
         self._ws = {}
         self._sn_plans = {}
 
-    def _call(self, symbol, op, nbytes, ref, *args):
+    def _call(self, symbol, op, nbytes, ref, *args, flops=0):
         fn = getattr(self.lib, symbol)
         with _DeviceGuard(ref):
-            _lib.check(_run(op, nbytes, ref, lambda: fn(*args, _stream(ref))), symbol)
+            _lib.check(_run(op, nbytes, ref, lambda: fn(*args, _stream(ref)), flops), symbol)
 
     def knn(self, p1, p2, len1, len2, K, r2):
         B, P1, D = p1.shape
@@ -364,7 +373,8 @@ class HipBackend:
         self._call("tpg_mlp_fwd", "mlp_fwd", 2 * P * (Cin + Cout), x,
                    _ptr(x), P, Cin, Cout, nseg, _ptr(ss_in), float(slope_in), _ptr(W), w_per_seg, _ptr(y), float(eps),
                    float(momentum), _ptr(running_mean), _ptr(running_var), _ptr(num_batches_tracked), _ptr(mean_shift),
-                   _ptr(gamma_out), _ptr(beta_out), _ptr(mean), _ptr(rstd), _ptr(ss_out), _ptr(ws))
+                   _ptr(gamma_out), _ptr(beta_out), _ptr(mean), _ptr(rstd), _ptr(ss_out), _ptr(ws),
+                   flops=2 * P * Cin * Cout)
         return y, mean, rstd, ss_out
 
     def rowbn_stats(self, x, eps, momentum, running_mean, running_var, num_batches_tracked, nseg, mean_shift):
@@ -417,7 +427,15 @@ class HipBackend:
                    _ptr(c12), Cc, nseg, _ptr(ci), _ptr(cb))
         return ci, cb
 
-    def mlp_dgrad(self, x_out, g_out, arg, K, cb_out, slope_out, x_in, ci_in, slope_in, W, nseg, need_affine):
+    def mlp_max_prep(self, gout, y, cb_out, slope_out, nseg):
+        """a * lrelu'(y) * gout per (group, channel): the MODE_MAX operand of mlp_dgrad / mlp_wgrad."""
+        rows, Cc = gout.shape
+        ag = torch.empty_like(gout)
+        self._call("tpg_mlp_max_prep", "mlp_max_prep", 6 * rows * Cc, gout, _ptr(gout), _ptr(y), _ptr(cb_out),
+                   float(slope_out), rows, Cc, nseg, _ptr(ag))
+        return ag
+
+    def mlp_dgrad(self, x_out, g_out, arg, K, cb_out, x_in, ci_in, slope_in, W, nseg, need_affine):
         """-> g_in (P,Cin) bf16, c12_in (nseg,2,Cin), dgamma_in, dbeta_in."""
         P, Cout = x_out.shape
         Cin = x_in.shape[1]
@@ -429,12 +447,12 @@ class HipBackend:
         dbeta = torch.empty(Cin, dtype=torch.float32, device=x_out.device) if need_affine else None
         ws = self._mlp_ws(x_out, max(Cin, Cout), nseg)
         self._call("tpg_mlp_dgrad", "mlp_dgrad", 2 * P * (Cout + 2 * Cin) + (0 if mode else 2 * P * Cout), x_out,
-                   _ptr(x_out), _ptr(g_out), _ptr(arg), int(K), _ptr(cb_out), float(slope_out), _ptr(x_in), _ptr(ci_in),
+                   _ptr(x_out), _ptr(g_out), _ptr(arg), int(K), _ptr(cb_out), _ptr(x_in), _ptr(ci_in),
                    float(slope_in), _ptr(W), w_per_seg, P, Cin, Cout, nseg, mode, _ptr(g_in), _ptr(c12), _ptr(dgamma),
-                   _ptr(dbeta), _ptr(ws))
+                   _ptr(dbeta), _ptr(ws), flops=2 * P * Cin * Cout)
         return g_in, c12, dgamma, dbeta
 
-    def mlp_wgrad(self, x_out, g_out, arg, K, cb_out, slope_out, x_in, ci_in, slope_in, nseg):
+    def mlp_wgrad(self, x_out, g_out, arg, K, cb_out, x_in, ci_in, slope_in, nseg):
         """-> dW (nseg,Cout,Cin) f32."""
         P, Cout = x_out.shape
         Cin = x_in.shape[1]
@@ -447,8 +465,8 @@ class HipBackend:
             ws = torch.empty(need, dtype=torch.float32, device=x_out.device)
             self._ws[key] = ws
         self._call("tpg_mlp_wgrad", "mlp_wgrad", 2 * P * (Cout + Cin) + (0 if mode else 2 * P * Cout), x_out,
-                   _ptr(x_out), _ptr(g_out), _ptr(arg), int(K), _ptr(cb_out), float(slope_out), _ptr(x_in), _ptr(ci_in),
-                   float(slope_in), P, Cin, Cout, nseg, mode, _ptr(dW), _ptr(ws))
+                   _ptr(x_out), _ptr(g_out), _ptr(arg), int(K), _ptr(cb_out), _ptr(x_in), _ptr(ci_in),
+                   float(slope_in), P, Cin, Cout, nseg, mode, _ptr(dW), _ptr(ws), flops=2 * P * Cin * Cout)
         return dW
 
     def mlp_bn_bwd_apply(self, g, x, ci, c12, nseg):
@@ -1047,19 +1065,16 @@ class _MlpTail(torch.autograd.Function):
         c12, dg, db = be.rowbn_bwd_sums(gout, xs[L], arg, out if K else None, K, means[L], rstds[L], gam[L], bet[L],
                                         slopes[L], need_aff[L], nseg)
         grads_aff[L] = (dg, db)
-        if L == 0:
-            raise RuntimeError("_MlpTail needs at least one fused layer")
-        g_next, arg_next, K_next = gout, arg, K
+        g_next, arg_next, K_next = None, arg, K
         for l in range(L, 0, -1):                    # layer l: x_{l-1} -> x_l
             _, cb = be.mlp_consts(means[l], rstds[l], gam[l], bet[l], c12, False, True)
             ci, _ = be.mlp_consts(means[l - 1], rstds[l - 1], gam[l - 1], bet[l - 1], None, True, False)
-            if l == L and not K:
-                # no max: the "arriving gradient" is dense but NOT yet activated; activate it here
-                raise RuntimeError("_MlpTail without the max over K is not wired")
+            if l == L:
+                # the arriving gradient lives on each group's arg-max row: a * lrelu'(y) * gout per (group, channel)
+                g_next = be.mlp_max_prep(gout, out, cb, slopes[L], nseg)
             if need_w[l - 1]:
-                grads_w[l - 1] = be.mlp_wgrad(xs[l], g_next, arg_next, K_next, cb, slopes[l], xs[l - 1], ci, slopes[l - 1],
-                                              nseg)
-            g_in, c12, dg, db = be.mlp_dgrad(xs[l], g_next, arg_next, K_next, cb, slopes[l], xs[l - 1], ci, slopes[l - 1],
+                grads_w[l - 1] = be.mlp_wgrad(xs[l], g_next, arg_next, K_next, cb, xs[l - 1], ci, slopes[l - 1], nseg)
+            g_in, c12, dg, db = be.mlp_dgrad(xs[l], g_next, arg_next, K_next, cb, xs[l - 1], ci, slopes[l - 1],
                                              Ws[l - 1], nseg, need_aff[l - 1])
             grads_aff[l - 1] = (dg, db)
             g_next, arg_next, K_next = g_in, None, 0
@@ -1077,7 +1092,7 @@ class _MlpTail(torch.autograd.Function):
 
 def mlp_tail_supported(x, channels, K):
     """Can `mlp_tail` run this tail?  bf16 rows on the GPU, supported channel pairs, a max over K."""
-    if not (x.is_cuda and x.dtype == torch.bfloat16 and 0 < K <= 256 and len(channels) >= 2):
+    if not (x.is_cuda and x.dtype == torch.bfloat16 and 0 < K <= 255 and len(channels) >= 2):
         return False
     return all((a, b) in MLP_CHANNELS for a, b in zip(channels[:-1], channels[1:]))
 
@@ -1093,6 +1108,7 @@ def mlp_tail(x0, bns, weights, slopes, K, nseg=1, shifts=None):
     shifts: per BatchNorm an optional bias of the preceding conv that was left out of its input."""
     L = len(weights)
     _need(len(bns) == L + 1 and len(slopes) == L + 1 and L >= 1, "mlp_tail: L weights, L+1 BatchNorms / slopes")
+    _need(all(0.0 <= float(sl) <= 1.0 for sl in slopes), "mlp_tail: LeakyReLU slopes in [0, 1] (lrelu = max(z, slope*z))")
     shifts = list(shifts) if shifts is not None else [None] * (L + 1)
     states, eps, moms = [], [], []
     for bn in bns:

@@ -229,6 +229,42 @@ def _segmentable(layers, x, K):
     return K <= 256 and x.shape[-1] % 8 == 0 and x.shape[-1] <= 1024
 
 
+def _parse_tail(layers):
+    """[BN, act, (conv, BN, act)*] -> (BatchNorms, convs, slopes), else None: the shape of tail the
+    fused MFMA kernels take (ops.mlp_tail)."""
+    bns, convs, slopes = [], [], []
+    i, n = 0, len(layers)
+    while i < n:
+        if i > 0:
+            if not isinstance(layers[i], nn.Conv2d) or layers[i].kernel_size != (1, 1):
+                return None
+            convs.append(layers[i])
+            i += 1
+        if i + 1 >= n or not isinstance(layers[i], (nn.BatchNorm2d, nn.BatchNorm1d)):
+            return None
+        bn, slope = layers[i], _act_slope(layers[i + 1])
+        if slope is None or not (bn.training and bn.momentum is not None and bn.affine):
+            return None
+        bns.append(bn)
+        slopes.append(slope)
+        i += 2
+    return (bns, convs, slopes) if convs else None
+
+
+FUSED_TAILS = [True]      # ops.mlp_tail for bf16 tails (off: the separate BN / GEMM launches, for A/B runs)
+
+
+def _try_fused_tail(bns, convs, slopes, x, K, nseg):
+    """x (P,C0) rows -> (P/K, C_L) through ops.mlp_tail, or None when the tail is not one it takes."""
+    if not (FUSED_TAILS[0] and x.is_cuda and x.dtype == torch.bfloat16 and rows_first()):
+        return None
+    chans = [x.shape[-1]] + [c.out_channels for c in convs]
+    if not ops.mlp_tail_supported(x, chans, K) or any(c.in_channels != a for c, a in zip(convs, chans[:-1])):
+        return None
+    Ws = [(conv_weights_seg(c, nseg) if nseg > 1 else conv_weight2d(c)).float() for c in convs]
+    return ops.mlp_tail(x, bns, Ws, slopes, K, nseg, shifts=[None] + [c.bias for c in convs])
+
+
 def mlp_tail_rows(layers, x, reduce_max=False, nseg=1):
     """Run [conv, (bn), act]* layers (from a given position) on rows x (...,K,C).
 
@@ -243,6 +279,12 @@ def mlp_tail_rows(layers, x, reduce_max=False, nseg=1):
         outs = [mlp_tail_rows(layers, xs, reduce_max) for xs in x.chunk(nseg, 0)]
         return torch.cat(outs, 0)
     x = x.reshape(-1, x.shape[-1])
+    if reduce_max:
+        parsed = _parse_tail(layers)
+        if parsed is not None:
+            out = _try_fused_tail(*parsed, x, K, nseg)
+            if out is not None:
+                return out.view(*lead, out.shape[-1])
     i, n, reduced, shift = 0, len(layers), False, None
     while i < n:
         m = layers[i]
@@ -547,6 +589,10 @@ class FlowEmbedding(nn.Module):
         B, N, K, _ = x.shape
         x = x.view(B * N * K, -1)
         nl = len(self.mlp_convs)
+        if all(bn.training and bn.momentum is not None for bn in self.mlp_bns):
+            out = _try_fused_tail(list(self.mlp_bns), list(self.mlp_convs)[1:], [0.01] * nl, x, K, 1)
+            if out is not None:
+                return out.view(B, N, -1)
         for l in range(nl):                                        # F.leaky_relu default slope 0.01
             if l:
                 x = rows_matmul(x, conv_weight2d(self.mlp_convs[l]))
@@ -574,6 +620,10 @@ class FlowEmbedding(nn.Module):
         K = x.shape[2]
         x = x.view(NB * N * K, -1)
         nl = len(self.mlp_convs)
+        if all(bn.training and bn.momentum is not None for bn in self.mlp_bns):
+            out = _try_fused_tail(list(self.mlp_bns), list(self.mlp_convs)[1:], [0.01] * nl, x, K, nseg)
+            if out is not None:
+                return out.view(NB, N, -1)
         for l in range(nl):                                        # F.leaky_relu default slope 0.01
             if l:
                 x = rows_matmul_seg(x, conv_weights_seg(self.mlp_convs[l], nseg))

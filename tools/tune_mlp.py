@@ -66,3 +66,26 @@ for name, P, nseg, Cin, Cout in SHAPES:
         print("unfused reference failed:", e)
     print(f"{name:22s} fused {us:8.1f} us  {nbytes / us / 1e3:7.1f} GB/s  {flops / us / 1e6:7.1f} TFLOP/s   "
           f"| stats+apply+GEMM+stats unfused {us0:8.1f} us")
+
+
+print()
+for name, P, nseg, Cin, Cout in SHAPES:
+    K = 32
+    x_in = torch.randn(P * nseg, Cin, device=dev).bfloat16()
+    x_out = torch.randn(P * nseg, Cout, device=dev).bfloat16()
+    W = torch.randn(nseg, Cout, Cin, device=dev) / Cin ** 0.5
+    cb = torch.rand(nseg, 4, Cout, device=dev)
+    ci = torch.rand(nseg, 4, Cin, device=dev)
+    ag = torch.randn(P * nseg // K, Cout, device=dev).bfloat16()
+    arg = torch.randint(0, K, (P * nseg // K, Cout), device=dev, dtype=torch.uint8)
+    gd = torch.randn(P * nseg, Cout, device=dev).bfloat16()
+    for mode, g, a, k in (("max", ag, arg, K), ("dense", gd, None, 0)):
+        us_d = timeit(lambda: hip.mlp_dgrad(x_out, g, a, k, cb, x_in, ci, 0.01, W, nseg, True))
+        us_w = timeit(lambda: hip.mlp_wgrad(x_out, g, a, k, cb, x_in, ci, 0.01, nseg))
+        bd = 2 * P * nseg * (Cout + 2 * Cin) + (2 * P * nseg * Cout if mode == "dense" else 0)
+        bw = 2 * P * nseg * (Cout + Cin) + (2 * P * nseg * Cout if mode == "dense" else 0)
+        print(f"{name:22s} {mode:5s} dgrad {us_d:8.1f} us {bd / us_d / 1e3:7.1f} GB/s | wgrad {us_w:8.1f} us {bw / us_w / 1e3:7.1f} GB/s")
+    g1 = torch.randn(P * nseg, Cin, device=dev).bfloat16()
+    c12 = torch.rand(nseg, 2, Cin, device=dev)
+    us = timeit(lambda: hip.mlp_bn_bwd_apply(g1, x_in, ci, c12, nseg))
+    print(f"{name:22s} bn_bwd_apply (C={Cin}) {us:8.1f} us {6 * P * nseg * Cin / us / 1e3:7.1f} GB/s")
