@@ -264,6 +264,8 @@ def main():
         run_steps(models, clips, 1, sync, amp_dtype, start=w)
         torch.cuda.synchronize()
         log(f"warm-up step {w + 1}/{args.warmup} done")
+    if world > 1 and GRAPHED is not None:
+        GRAPHED.timing = []          # per step: [first graph, gradient all-reduce, second graph] in us (HIP events)
     ddp.barrier()
     torch.cuda.synchronize()
     t0 = time.perf_counter()
@@ -292,6 +294,15 @@ def main():
                              "step: tests/test_graph_gpu.py::test_bf16_graph_against_fp32_eager_at_bench_size",
                    "parallelism": f"dp{world}", "step_mode": mode, "last_losses": last},
     }
+    if world > 1 and GRAPHED is not None and getattr(GRAPHED, "timing", None):
+        # what one step of this rank spent where: explains the scaling number the driver computes
+        t = torch.tensor(GRAPHED.timing, dtype=torch.float64, device=device).mean(0)
+        torch.distributed.all_reduce(t, op=torch.distributed.ReduceOp.MAX)
+        names = ["graph_grads_us", "allreduce_us", "graph_apply_us"]
+        line["multi_gpu_breakdown"] = {n: round(float(v), 1) for n, v in zip(names, t.tolist())}
+        line["multi_gpu_breakdown"]["note"] = ("mean over the timed steps, max over ranks; HIP events on the step's stream: "
+                                               "forward+backward graph, the ONE flat gradient all-reduce (RCCL), optimizer graph")
+        log(f"rank {rank}: per-step breakdown {line['multi_gpu_breakdown']}")
     if rank == 0 and world == 1 and not args.no_extra:
         extra, table = roofline_leg(models, clips, min(args.steps, 5), sync, amp_dtype)
         line.update(extra)

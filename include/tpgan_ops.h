@@ -55,6 +55,16 @@ int tpg_knn_f32(const float *p1, const float *p2, const int64_t *len1,
                 const int64_t *len2, int B, int P1, int P2, int D, int K,
                 float r2, float *dist, int64_t *idx, void *stream);
 
+/* The same radius search (r > 0, D = 3, K <= 64) on a UNIFORM GRID, for clouds where the exhaustive
+ * kernel stops being free (loss.py:256-265 at 16384 points per cloud; the 10^4..10^5-point rollout,
+ * upsampling_network.py:159-174): cells of edge max(r, extent/64), points counting-sorted by cell,
+ * one wave per query over its 27 neighbour cells.  Results are bit-identical to tpg_knn_f32 with
+ * r2 = fp32(r)*fp32(r): same distance arithmetic, same (dist, idx) selection key, -1 / -1 padding.
+ * ws: tpg_frnn_grid_workspace_bytes(B, P2) bytes, 256-byte aligned. */
+size_t tpg_frnn_grid_workspace_bytes(int B, int P2);
+int tpg_frnn_grid_f32(const float *p1, const float *p2, const int64_t *len1, const int64_t *len2, int B, int P1,
+                      int P2, int K, float r, float *dist, int64_t *idx, void *ws, void *stream);
+
 /* Chamfer nearest-neighbour search in both directions (D = 3).
  * Replaces chamferdist.ChamferDistance.forward -- loss.py:125-127,176-181.
  * src (B,N,3), tgt (B,M,3) -> d1,i1 (B,N), d2,i2 (B,M). */
@@ -218,13 +228,13 @@ int tpg_mlp_fwd(const void *x, long long P, int Cin, int Cout, int nseg, const f
 /* Backward of such a layer, x_in (P,Cin) -> x_out (P,Cout) = W . lrelu(BN_in(x_in)), followed by
  * BN_out (+ LeakyReLU; + max over groups of K rows on a tail's last layer).  With BN_out's backward
  * sums known (c12), the gradient of x_out is elementwise in saved tensors,
- *     dx_out = a*gg + e - f*x_out      (a, bz, e, f per channel: tpg_mlp_consts, cb (nseg,4,Cout))
+ *     dx_out = a*gg - f*(x_out - mu) + e      (a, f*mu, e, f per channel: tpg_mlp_consts, cb (nseg,4,Cout))
  * and is never stored: it is rebuilt in the MFMA operand prologue of both gradient kernels.
  *   mode 0 DENSE: gg = g_out (P,Cout) bf16, the activated gradient written by the next layer's dgrad
  *   mode 1 MAX  : g_out (P/K,Cout) bf16 = a * lrelu'(y) * (gradient of the max output), one value per
  *                 (group, channel), made by tpg_mlp_max_prep from that gradient and the forward's output y;
  *                 arg = the arg-max bytes: the value belongs to row arg of its group, the others get 0
- * The MFMA operand the kernels build is d = dx_out - e (one fma per element); e enters as a rank-one
+ * The MFMA operand the kernels build is the centred d = dx_out - e (one fma per element); e enters as a rank-one
  * term (e^T W per input channel in tpg_mlp_dgrad's epilogue, e (x) sum_rows a_in in tpg_mlp_wgrad).
  * tpg_mlp_dgrad: g_in (P,Cin) bf16 = (dx_out . W) * lrelu'(z_in) and BN_in's backward sums:
  *   c12_in (nseg,2,Cin), dgamma_in / dbeta_in (Cin, summed over segments, may be NULL).

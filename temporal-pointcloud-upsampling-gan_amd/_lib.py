@@ -20,6 +20,7 @@ _L = C.c_longlong
 # symbol -> argtypes (restype is always int except the two string getters)
 SIGNATURES = {
     "tpg_knn_f32": [_P, _P, _P, _P, _I, _I, _I, _I, _I, _F, _P, _P, _P],
+    "tpg_frnn_grid_f32": [_P, _P, _P, _P, _I, _I, _I, _I, _F, _P, _P, _P, _P],
     "tpg_chamfer_fwd_f32": [_P, _P, _I, _I, _I, _P, _P, _P, _P, _P],
     "tpg_chamfer_bwd_f32": [_P, _P, _I, _I, _I, _P, _P, _P, _P, _P, _P, _P],
     "tpg_fps_f32": [_P, _I, _I, _I, _P, _P, _P],
@@ -53,7 +54,7 @@ SIGNATURES = {
 }
 SIZE_GETTERS = ("tpg_rowbn_workspace_bytes", "tpg_mlp_workspace_bytes")
 OTHER_GETTERS = ("tpg_spectral_norm_multi_stride", "tpg_spectral_norm_multi_bwd_scratch",
-                 "tpg_mlp_wgrad_workspace_bytes")
+                 "tpg_mlp_wgrad_workspace_bytes", "tpg_frnn_grid_workspace_bytes")
 STRING_GETTERS = ("tpg_version", "tpg_target_arch")
 
 STATUS = {0: "TPG_OK", -1: "TPG_ERR_ARG", -2: "TPG_ERR_LAUNCH", -3: "TPG_ERR_UNSUPPORTED"}
@@ -90,6 +91,8 @@ def load():
     lib.tpg_spectral_norm_multi_bwd_scratch.restype = C.c_longlong
     lib.tpg_mlp_wgrad_workspace_bytes.argtypes = [C.c_longlong, C.c_int, C.c_int, C.c_int]
     lib.tpg_mlp_wgrad_workspace_bytes.restype = C.c_size_t
+    lib.tpg_frnn_grid_workspace_bytes.argtypes = [C.c_int, C.c_int]
+    lib.tpg_frnn_grid_workspace_bytes.restype = C.c_size_t
     _lib = lib
     return lib
 

@@ -5,8 +5,8 @@
 // gcn_lib/pointnet/gcn.py:207,261 and discriminator.py:270,273; gather_operation
 // at discriminator.py:131-137).
 //
-// ball_query  -- one wave64 per query.  The cloud is staged once per workgroup
-//   into LDS as SoA (conflict-free ds_read_b32, coalesced HBM/L2 reads); the 64
+// ball_query  -- one wave64 per 4 queries, points read straight from L2
+//   (see the kernel); the 64
 //   lanes test 64 consecutive points per step, a ballot gives the in-radius
 //   mask, popcount-prefix gives each hit its output slot in INDEX order, and the
 //   wave stops as soon as nsample hits are found.  Upstream runs one thread per
@@ -22,19 +22,26 @@
 namespace {
 
 // ---------------------------------------------------------------- ball query
-constexpr int BQ_CHUNK = 4096;  // points per LDS stage (48 KiB)
+// One wave per BQ_QPW queries, no LDS and no barrier: the 64 lanes read 64 consecutive points of the
+// cloud straight from L2 (a cloud is 48 KB .. 200 KB and every wave walks it from index 0, so after the
+// first touch it is all cache hits; the next step's points are loaded while the current ones are
+// tested), each point is tested against the wave's BQ_QPW queries, a ballot gives the in-radius mask,
+// popcount-prefix the output slot in INDEX order -- and the wave STOPS as soon as its queries have
+// their nsample hits.  At the step's radii that is after 150..500 of 4096 points: staging the whole
+// cloud in LDS per workgroup (the first form of this kernel: 48 KB x 64 workgroups per cloud, 2.8x
+// the algorithmic traffic at the memory side, a barrier per chunk) cost more than the search.
 constexpr int BQ_WAVES = 4;
-constexpr int BQ_QPW = 4;       // queries per wave
+constexpr int BQ_QPW = 4;       // queries per wave (one load of a point serves all of them)
 
 __global__ __launch_bounds__(BQ_WAVES * 64) void ball_query_kernel(
     const float *__restrict__ xyz, const float *__restrict__ new_xyz, int N, int S, float r2,
     int nsample, int32_t *__restrict__ idx) {
-    __shared__ float sx[BQ_CHUNK], sy[BQ_CHUNK], sz[BQ_CHUNK];
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int b = blockIdx.y;
     const float *x = xyz + (size_t)b * N * 3;
     const int q0 = (blockIdx.x * BQ_WAVES + wave) * BQ_QPW;
+    if (q0 >= S) return;
 
     float qx[BQ_QPW], qy[BQ_QPW], qz[BQ_QPW];
     int cnt[BQ_QPW], first[BQ_QPW];
@@ -46,34 +53,30 @@ __global__ __launch_bounds__(BQ_WAVES * 64) void ball_query_kernel(
         cnt[u] = (q0 + u < S) ? 0 : nsample;  // out-of-range queries are "done"
         first[u] = 0;
     }
-
-    for (int c0 = 0; c0 < N; c0 += BQ_CHUNK) {
-        const int cn = min(BQ_CHUNK, N - c0);
-        if (c0) __syncthreads();
-        for (int e = tid; e < cn * 3; e += BQ_WAVES * 64) {
-            const float v = x[(size_t)c0 * 3 + e];
-            const int p = e / 3, comp = e - p * 3;
-            (comp == 0 ? sx : comp == 1 ? sy : sz)[p] = v;
-        }
-        __syncthreads();
+    const tpg_u64 below = (1ull << lane) - 1ull;
+    // this lane's point of the current step (clamped loads: the tail lanes are masked by p < N)
+    int pc = min(lane, N - 1);
+    float px = x[(size_t)pc * 3], py = x[(size_t)pc * 3 + 1], pz = x[(size_t)pc * 3 + 2];
+    for (int base = 0; base < N; base += 64) {
+        const int pn = min(base + 64 + lane, N - 1);           // next step's point travels during this one
+        const float nx = x[(size_t)pn * 3], ny = x[(size_t)pn * 3 + 1], nz = x[(size_t)pn * 3 + 2];
+        const int p = base + lane;
+        bool open = false;
 #pragma unroll
         for (int u = 0; u < BQ_QPW; ++u) {
-            if (cnt[u] >= nsample) continue;  // wave-uniform
-            int32_t *out = idx + ((size_t)b * S + (q0 + u)) * nsample;
-            for (int base = 0; base < cn; base += 64) {
-                const int p = base + lane;
-                bool in = false;
-                if (p < cn) in = tpg_sq3(qx[u], qy[u], qz[u], sx[p], sy[p], sz[p]) < r2;
-                const tpg_u64 mask = __ballot(in);
-                if (mask) {
-                    if (cnt[u] == 0) first[u] = c0 + base + __builtin_ctzll(mask);
-                    const int pos = cnt[u] + __popcll(mask & ((1ull << lane) - 1ull));
-                    if (in && pos < nsample) out[pos] = c0 + p;
-                    cnt[u] += __popcll(mask);
-                    if (cnt[u] >= nsample) break;
-                }
+            if (cnt[u] >= nsample) continue;                   // wave-uniform
+            const bool in = p < N && tpg_sq3(qx[u], qy[u], qz[u], px, py, pz) < r2;
+            const tpg_u64 mask = __ballot(in);
+            if (mask) {
+                if (cnt[u] == 0) first[u] = base + __builtin_ctzll(mask);
+                const int pos = cnt[u] + __popcll(mask & below);
+                if (in && pos < nsample) idx[((size_t)b * S + (q0 + u)) * nsample + pos] = p;
+                cnt[u] += __popcll(mask);
             }
+            open = open || cnt[u] < nsample;
         }
+        if (!open) break;                                      // every query of the wave is full
+        px = nx; py = ny; pz = nz;
     }
 #pragma unroll
     for (int u = 0; u < BQ_QPW; ++u) {

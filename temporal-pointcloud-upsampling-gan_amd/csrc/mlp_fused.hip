@@ -335,16 +335,19 @@ __global__ void mlp_scale_shift_kernel(const float *__restrict__ mean, const flo
 // Downstream of x_out sits BN_out (+ LeakyReLU, + max over K on the last layer).  With BN_out's
 // backward sums c1 = sum(gg)/P, c2 = sum(gg*xhat)/P known, the gradient of x_out is elementwise:
 //
-//     dx_out = a*gg + e - f*x_out        a = gamma*rstd,  f = a*rstd*c2,  e = a*(mu*rstd*c2 - c1)
+//     dx_out = a*gg - f*(x_out - mu) + e      a = gamma*rstd,  f = a*rstd*c2,  e = -a*c1
 //
 // gg = the gradient arriving at BN_out's output, already multiplied by lrelu'(z):
 //   MODE_DENSE  g_out (P,COUT) bf16, produced by the NEXT layer's dgrad epilogue;
 //   MODE_MAX    the last layer: a*gg lives on each group's arg-max row only; g_out (P/K,COUT) bf16 holds
 //               it per (group, channel) (mlp_max_prep_kernel: a * lrelu'(y) * gout from the forward's
 //               output y), arg the row it belongs to.
-// dx_out is never stored.  The MFMA operand the kernels build is  d = dx_out - e  (one fma per
-// element, plus a compare / select for the arg-max row); the constant e enters as a rank-one term:
-// e^T W per input channel in the data gradient's epilogue, e (x) sum_rows(a_in) in the weight gradient.
+// dx_out is never stored.  The MFMA operand the kernels build is  d = dx_out - e = a*gg - f*(x - mu)
+// (one fma per element -- fma(-f, x, f*mu) -- plus a compare / select for the arg-max row); d is
+// the CENTRED gradient, so its bf16 rounding is relative to its own size (with the uncentred
+// e - f*x a channel with |mu| >> sigma lost the bits that matter).  The constant e enters as a rank-one
+// term: e^T W per input channel in the data gradient's epilogue, e (x) sum_rows(a_in) in the weight
+// gradient.
 enum { MODE_DENSE = 0, MODE_MAX = 1 };
 
 __device__ __forceinline__ void ld8(const float *p, float (&v)[8]) {
@@ -352,11 +355,11 @@ __device__ __forceinline__ void ld8(const float *p, float (&v)[8]) {
     v[0] = a.x; v[1] = a.y; v[2] = a.z; v[3] = a.w; v[4] = b.x; v[5] = b.y; v[6] = b.z; v[7] = b.w;
 }
 
-// 8 consecutive channels of d = dx_out - e of one row -> 4 packed bf16 pairs.
-//   DENSE: d = a*g - f*x          MAX: d = (arg == k ? ag : 0) - f*x     (gr = g resp. ag = a*gg)
+// 8 consecutive channels of d = dx_out - e of one row -> 4 packed bf16 pairs (fm = f*mu).
+//   DENSE: d = a*g - f*x + fm          MAX: d = (arg == k ? ag : 0) - f*x + fm     (gr = g resp. ag = a*gg)
 template <int MODE>
 __device__ __forceinline__ void d_out8(const uint4 xr, const uint4 gr, const uint2 ar, int k, const float (&a)[8],
-                                       const float (&f)[8], unsigned (&o)[4]) {
+                                       const float (&f)[8], const float (&fm)[8], unsigned (&o)[4]) {
     const unsigned xw[4] = {xr.x, xr.y, xr.z, xr.w}, gw[4] = {gr.x, gr.y, gr.z, gr.w};
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
@@ -366,11 +369,12 @@ __device__ __forceinline__ void d_out8(const uint4 xr, const uint4 gr, const uin
             const int j = 2 * i + h;
             const float x = h ? bf16_hi(xw[i]) : bf16_lo(xw[i]);
             const float g = h ? bf16_hi(gw[i]) : bf16_lo(gw[i]);
+            const float c = __builtin_fmaf(-f[j], x, fm[j]);          // -f * (x - mu)
             if (MODE == MODE_MAX) {
                 const int ak = (int)__builtin_amdgcn_ubfe(j < 4 ? ar.x : ar.y, 8 * (j & 3), 8);
-                v[h] = __builtin_fmaf(-f[j], x, ak == k ? g : 0.0f);
+                v[h] = c + (ak == k ? g : 0.0f);
             } else {
-                v[h] = __builtin_fmaf(a[j], g, -f[j] * x);
+                v[h] = __builtin_fmaf(a[j], g, c);
             }
         }
         o[i] = pack_bf16x2(v[0], v[1]);
@@ -407,7 +411,7 @@ __global__ void mlp_max_prep_kernel(const __hip_bfloat16 *__restrict__ g, const 
 
 // data gradient: g_in = ((dx_out) . W) * lrelu'(z_in), rounded to bf16 and stored, plus the partial
 // sums of BN_in's backward (sum g_in | sum g_in * (x_in - mu); the finalize multiplies by rstd).
-// grid (G, nseg).  cbo (nseg,4,COUT) = a|bz|e|f of BN_out; cbi (nseg,4,CIN) = sc|sh|mu|rs of BN_in.
+// grid (G, nseg).  cbo (nseg,4,COUT) = a|f*mu|e|f of BN_out; cbi (nseg,4,CIN) = sc|sh|mu|rs of BN_in.
 // part (nseg, G, 2, CIN).
 template <int CIN, int COUT, int MODE, int STRIPS, int OCC>
 __global__ __launch_bounds__(ML_THREADS, OCC) void mlp_dgrad_kernel(
@@ -422,8 +426,8 @@ __global__ __launch_bounds__(ML_THREADS, OCC) void mlp_dgrad_kernel(
     constexpr int WROW = COUT + ML_WPAD;
     extern __shared__ __attribute__((aligned(16))) unsigned char ml_smem[];
     unsigned short *wl = reinterpret_cast<unsigned short *>(ml_smem);                  // [CIN][WROW]: W^T
-    float *cst = reinterpret_cast<float *>(ml_smem + (size_t)CIN * WROW * 2);          // a[COUT] | f[COUT] | e[COUT]
-    float *bias = cst + 3 * COUT;                                                      // [CIN]: e^T W
+    float *cst = reinterpret_cast<float *>(ml_smem + (size_t)CIN * WROW * 2);          // a | f | e | f*mu, [COUT] each
+    float *bias = cst + 4 * COUT;                                                      // [CIN]: e^T W
     float *red = bias + CIN;                                                           // [ML_WAVES][2][CIN]
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int li = lane & 15, lq = lane >> 4;
@@ -451,6 +455,7 @@ __global__ __launch_bounds__(ML_THREADS, OCC) void mlp_dgrad_kernel(
             cst[c] = cb[c];                       // a
             cst[COUT + c] = cb[3 * COUT + c];     // f
             cst[2 * COUT + c] = cb[2 * COUT + c]; // e
+            cst[3 * COUT + c] = cb[COUT + c];     // f * mu
         }
     }
     __syncthreads();
@@ -525,16 +530,17 @@ __global__ __launch_bounds__(ML_THREADS, OCC) void mlp_dgrad_kernel(
             for (int t = 0; t < TI; ++t) acc[st][t] = f32x4{0.0f, 0.0f, 0.0f, 0.0f};
 #pragma unroll
         for (int s = 0; s < KS; ++s) {
-            float ca[8], cf[8];
+            float ca[8], cf[8], cfm[8];
             if (MODE == MODE_DENSE) ld8(cst + 32 * s + 8 * lq, ca);
             ld8(cst + COUT + 32 * s + 8 * lq, cf);
+            ld8(cst + 3 * COUT + 32 * s + 8 * lq, cfm);
             bf16x8 afrag[STRIPS];
 #pragma unroll
             for (int st = 0; st < STRIPS; ++st) {
                 const long long row = row_base + st * 16 + li;
                 union { unsigned u[4]; bf16x8 v; } cv;
                 d_out8<MODE>(xraw[st][s], graw[st][s], araw[st][s], MODE == MODE_MAX ? (int)((unsigned)row % (unsigned)K) : 0, ca,
-                             cf, cv.u);
+                             cf, cfm, cv.u);
                 if (row >= P) { cv.u[0] = 0u; cv.u[1] = 0u; cv.u[2] = 0u; cv.u[3] = 0u; }
                 afrag[st] = cv.v;
             }
@@ -651,7 +657,7 @@ __global__ __launch_bounds__(ML_THREADS) void mlp_bwd_finalize_kernel(const floa
 
 // (mean, rstd, gamma, beta[, c12]) -> the folded constants the kernels read:
 //   ci (nseg,4,C) = sc | sh | mu | rs            (input side: activation recompute, xhat)
-//   cb (nseg,4,C) = a | bz | e | f               (output side: dx = a*gg + e - f*x), needs c12
+//   cb (nseg,4,C) = a | f*mu | e | f             (output side: dx = a*gg - f*(x - mu) + e), needs c12
 __global__ void mlp_consts_kernel(const float *__restrict__ mean, const float *__restrict__ rstd,
                                   const float *__restrict__ gamma, const float *__restrict__ beta,
                                   const float *__restrict__ c12, int C, int nseg, float *__restrict__ ci,
@@ -669,7 +675,8 @@ __global__ void mlp_consts_kernel(const float *__restrict__ mean, const float *_
     if (cb) {
         const float c1 = c12[((size_t)seg * 2 + 0) * C + c], c2 = c12[((size_t)seg * 2 + 1) * C + c];
         float *o = cb + (size_t)seg * 4 * C + c;
-        o[0] = a; o[C] = bz; o[2 * C] = a * (mu * rs * c2 - c1); o[3 * C] = a * rs * c2;
+        const float f = a * rs * c2;
+        o[0] = a; o[C] = f * mu; o[2 * C] = -a * c1; o[3 * C] = f;
     }
 }
 
@@ -726,9 +733,10 @@ __global__ __launch_bounds__(ML_THREADS, OCC) void mlp_wgrad_kernel(
     else { g_out += (size_t)seg * (P / K) * COUT; arg += (size_t)seg * (P / K) * COUT; }
     // this thread's chunks and their constants
     const int dch = tid % DCH, drow = tid / DCH, ach = tid % ACH, arow = tid / ACH;
-    float ca[8], cf[8], sc[8], sh[8], asum[8];
+    float ca[8], cf[8], cfm[8], sc[8], sh[8], asum[8];
     ld8(cbo + ((size_t)seg * 4 + 0) * COUT + 8 * dch, ca);
     ld8(cbo + ((size_t)seg * 4 + 3) * COUT + 8 * dch, cf);
+    ld8(cbo + ((size_t)seg * 4 + 1) * COUT + 8 * dch, cfm);
     ld8(cbi + ((size_t)seg * 4 + 0) * CIN + 8 * ach, sc);
     ld8(cbi + ((size_t)seg * 4 + 1) * CIN + 8 * ach, sh);
 #pragma unroll
@@ -769,7 +777,7 @@ __global__ __launch_bounds__(ML_THREADS, OCC) void mlp_wgrad_kernel(
             const int r = drow + i * DR;
             const long long row = r0 + r;
             unsigned o[4];
-            d_out8<MODE>(xr[i], gr[i], ar[i], MODE == MODE_MAX ? (int)((unsigned)(row < P ? row : P - 1) % (unsigned)K) : 0, ca, cf, o);
+            d_out8<MODE>(xr[i], gr[i], ar[i], MODE == MODE_MAX ? (int)((unsigned)(row < P ? row : P - 1) % (unsigned)K) : 0, ca, cf, cfm, o);
             if (row >= P) { o[0] = 0u; o[1] = 0u; o[2] = 0u; o[3] = 0u; }
             *reinterpret_cast<uint4 *>(dxt + (size_t)r * DROW + 8 * dch) = make_uint4(o[0], o[1], o[2], o[3]);
         }
@@ -966,7 +974,7 @@ int fwd_launch(const void *x, long long P, int nseg, const float *ss, float slop
 // half the LDS run alone on their CU and may use the whole register file
 template <int CIN, int COUT> constexpr int bwd_strips() { return (CIN == 64 && COUT <= 128) ? 2 : 1; }
 template <int CIN, int COUT> constexpr size_t dgrad_smem() {
-    return (size_t)CIN * (COUT + ML_WPAD) * 2 + sizeof(float) * (3 * COUT + CIN + ML_WAVES * 2 * CIN);
+    return (size_t)CIN * (COUT + ML_WPAD) * 2 + sizeof(float) * (4 * COUT + CIN + ML_WAVES * 2 * CIN);
 }
 template <int CIN, int COUT> constexpr size_t wgrad_smem() {
     return (size_t)WG_ROWS * ((COUT + WG_PAD) + (CIN + WG_PAD)) * 2 + sizeof(float) * (ML_THREADS / (CIN / 8)) * CIN;

@@ -520,18 +520,32 @@ class GraphedFluidStep:
         self._dev_i.copy_(self._host_i, non_blocking=True)
         for d, t in zip(self._snap, self._state):                       # pre-step snapshot (18 MB, one copy
             d.copy_(t)                                                  # per dtype: the state is flat)
+        marks = None
         if launch_eagerly:
             self._run_eager(update_D)
         else:
+            timing = getattr(self, "timing", None)      # a list: per-step (graph-1, all-reduce, graph-2) us
+            if timing is not None:
+                st = torch.cuda.current_stream(self.dev)
+                marks = [torch.cuda.Event(enable_timing=True)]
+                marks[0].record(st)
             for g, flat in self._graphs[update_D]:
                 g.replay()
+                if marks is not None:
+                    marks.append(torch.cuda.Event(enable_timing=True))
+                    marks[-1].record(st)
                 if flat is not None:
                     self.sync.sum_flat(flat)            # the ONE collective of the step's gradients
+                    if marks is not None:
+                        marks.append(torch.cuda.Event(enable_timing=True))
+                        marks[-1].record(st)
         # multi-GPU: the decision to leave the graph path must be COLLECTIVE -- the eager step issues
         # other all-reduces than the replay -- and it is: the two-graph form has summed the flag over
         # the ranks inside its one all-reduce
         viol = self.viol
         out = torch.cat([self.report, viol.reshape(1)]).cpu().tolist()   # the step's one host sync
+        if marks is not None:
+            self.timing.append([1e3 * a.elapsed_time(b) for a, b in zip(marks[:-1], marks[1:])])
         if out[6] != 0.0:
             # not the static regime: put everything back and take the general path with the same draws
             for d, t in zip(self._snap, self._state):

@@ -207,7 +207,7 @@ def capture_losses():
 # order is pinned piecewise -- generator, discriminators, losses, gradients of both orders -- and
 # only the reference order is pinned on whole steps.)
 JITTER = 1e-7
-STABLE = 2e-5
+STABLE = 1e-4
 STEP_BATCH = 4    # clips per step fixture: with 2 the heads' BatchNorm1d sees xhat = +-1 (a sign network)
 
 
@@ -253,7 +253,7 @@ def _ref_step(kind, clip_seed, noise_seed=None):
     return losses, before, (G, Ds, Dt), low, high
 
 
-def step_fixture(kind, first_seed=31, tries=12):
+def step_fixture(kind, first_seed=31, tries=24):
     """A full adversarial step of the reference: losses + parameters after one SGD step.
 
     The GAN terms of a step of UNTRAINED networks can sit on a discrete decision (an FPS pick, a
@@ -262,19 +262,40 @@ def step_fixture(kind, first_seed=31, tries=12):
     (two clips, seed 31), whose `tempo_G_loss` read 0.96814 or 0.94807 under a 1e-7 jitter of the
     inputs -- and with two clips the heads' BatchNorm1d is a sign network on top of that.  Such a
     clip pins nothing but the reference's own summation order.  So the fixtures hold four clips
-    and the clip seed is SELECTED: the first one for which three runs of the reference with
-    coordinates jittered by JITTER reproduce every loss of the clean run to STABLE (the steadiest of
-    `tries` seeds otherwise; the measured sensitivity is stored as `jitter_sensitivity`).  Any
+    and the clip seed is SELECTED: the first one for which six probe runs of the reference -- three
+    with coordinates jittered by JITTER, one with oneDNN off, two with other thread counts --
+    reproduce every loss of the clean run to STABLE (the steadiest of `tries` seeds otherwise; the
+    measured sensitivity is stored as `jitter_sensitivity`).  Any
     faithful implementation (other GEMM order, other device, first layer before the gather) then
     lands on the same decisions."""
     best = None
     for clip_seed in range(first_seed, first_seed + tries):
         losses = _ref_step(kind, clip_seed)[0]
         worst = 0.0
-        for noise_seed in (1, 2, 3):
-            jl = _ref_step(kind, clip_seed, noise_seed)[0]
+        # probes: input jitter, and the reference's own arithmetic in another summation order (oneDNN
+        # off = native convolutions; one thread = other GEMM blocking) -- the first batch-4 fixture
+        # (fluid, seed 37) passed three jitters and still read 1.1048 / 1.6758 with 8 oneDNN threads
+        # and 1.1117 / 1.7294 everywhere else (1 thread, oneDNN off, this repo on CPU and GPU)
+        probes = [("jitter", 1), ("jitter", 2), ("jitter", 3), ("native", None), ("threads", 1), ("threads", 3)]
+        for what, arg in probes:
+            if what == "jitter":
+                jl = _ref_step(kind, clip_seed, arg)[0]
+            elif what == "native":
+                torch.backends.mkldnn.enabled = False
+                try:
+                    jl = _ref_step(kind, clip_seed)[0]
+                finally:
+                    torch.backends.mkldnn.enabled = True
+            else:
+                torch.set_num_threads(arg)
+                try:
+                    jl = _ref_step(kind, clip_seed)[0]
+                finally:
+                    torch.set_num_threads(8)
             worst = max(worst, max(abs(jl[k] - losses[k]) / max(1.0, abs(losses[k])) for k in losses))
-        print(f"{kind}: clip seed {clip_seed}: worst loss change under {JITTER:g} jitter {worst:.2e}", flush=True)
+            if worst > STABLE:
+                break
+        print(f"{kind}: clip seed {clip_seed}: worst loss change under the probes {worst:.2e}", flush=True)
         if best is None or worst < best[0]:
             best = (worst, clip_seed)
         if worst <= STABLE:

@@ -545,3 +545,56 @@ def test_dataset_fps_matches_the_reference_fixture(hip):
         pts, k, start = g[f"{tag}/pts"], int(g[f"{tag}/k"]), int(g[f"{tag}/start"])
         got = ops.farthest_point_sampling(dev(pts), k, initial_idx=start).cpu().numpy()
         assert np.array_equal(got, g[f"{tag}/idx"]), tag
+
+
+# ------------------------------------------------------------------ grid radius search (csrc/frnn_grid.hip)
+def _grid(hip, p1, p2, K, r, len1=None, len2=None):
+    import tpgan_amd.ops as ops
+    old = hip.GRID_MIN_POINTS, hip.GRID_MIN_PAIRS
+    hip.GRID_MIN_POINTS, hip.GRID_MIN_PAIRS = 1, 0.0             # force the grid whatever the size
+    try:
+        l1 = None if len1 is None else dev(np.asarray(len1, np.int64))
+        l2 = None if len2 is None else dev(np.asarray(len2, np.int64))
+        return hip.knn(dev(p1), dev(p2), l1, l2, K, ops.radius_sq(r), r=r)
+    finally:
+        hip.GRID_MIN_POINTS, hip.GRID_MIN_PAIRS = old
+
+
+@pytest.mark.parametrize("B,P1,P2,K,r", [
+    (2, 512, 4096, 1, 0.0475), (2, 4096, 4096, 16, 0.035), (1, 16384, 16384, 16, 0.035), (1, 4096, 16384, 1, 0.0475),
+    (3, 256, 256, 32, 2.0), (1, 100, 300, 8, 0.01), (1, 64, 64, 64, 0.2), (1, 2000, 65536, 32, 0.04), (2, 33, 77, 5, 0.3)])
+def test_frnn_grid_bit_exact(hip, B, P1, P2, K, r):
+    """The uniform-grid radius search against the oracle: same indices, same distances, same -1 padding."""
+    rng = np.random.default_rng(P1 + P2 + K)
+    p2 = fluid(rng, B, P2)
+    p1 = p2.copy() if P1 == P2 else fluid(rng, B, P1, scale=0.3 * max(1.0, (P2 / 4096.0) ** (1.0 / 3.0)))   # some queries outside the box
+    if P2 > 20:
+        p2[0, 5] = p2[0, 7]                    # exact duplicates: ties resolved by index
+        if P1 == P2:
+            p1 = p2.copy()
+    d, i = _grid(hip, p1, p2, K, r)
+    rd, ri = R.knn(p1, p2, K, r=r)
+    assert np.array_equal(i.cpu().numpy(), ri)
+    assert np.array_equal(d.cpu().numpy(), rd)
+
+
+def test_frnn_grid_ragged_dummies_and_far_queries(hip):
+    """lengths1 / lengths2, 999-dummies in the searched cloud (the box grows, the cells with it: still
+    exact), queries far outside the box (no neighbour: all -1), a degenerate cloud of identical points."""
+    import tpgan_amd.ops as ops
+    rng = np.random.default_rng(3)
+    p2 = fluid(rng, 3, 3000)
+    p1 = fluid(rng, 3, 700)
+    p2[1, 2500:] = 999.0
+    p1[0, :5] = 50.0
+    p2[2, :] = p2[2, 0]
+    d, i = _grid(hip, p1, p2, 16, 0.06, len1=[700, 650, 10], len2=[3000, 2800, 3000])
+    rd, ri = R.knn(p1, p2, 16, lengths1=[700, 650, 10], lengths2=[3000, 2800, 3000], r=0.06)
+    assert np.array_equal(i.cpu().numpy(), ri) and np.array_equal(d.cpu().numpy(), rd)
+    assert (ri[0, :5] == -1).all()
+    # through the public entry: the size switch picks the grid for a large searched cloud
+    big = fluid(rng, 1, 20000)
+    assert 1 * 4000 * 20000 >= hip.GRID_MIN_PAIRS
+    dd, ii = ops.neighbour_search(dev(big[:, :4000]), dev(big), 8, r=0.05)
+    rd, ri = R.knn(big[:, :4000], big, 8, r=0.05)
+    assert np.array_equal(ii.cpu().numpy(), ri) and np.array_equal(dd.cpu().numpy(), rd)
