@@ -23,8 +23,13 @@ GOLD = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
 # the CPU run the goldens come from; training-mode BatchNorm on untrained nets multiplies absolute
 # differences by up to 1/sqrt(eps) = 316): measured values are printed by the tests
 GPU_TRAIN_TOL = 5e-3
-GPU_GAN_TOL = 5e-3
-GPU_STATE_TOL = 5e-4
+# whole steps, on fixtures whose clip was selected for stability (capture_goldens.step_fixture): the six
+# losses agree to ~2e-5 on every path (measured: fluid tempo_G 1.019007 reference / 1.019016 default order
+# on CPU / 1.019018, 1.019023 on the GPU); held at 5e-4.  Parameters after the SGD step = gradients: a
+# max-pool winner near a tie may differ between summation orders and moves single entries by lr * O(1),
+# so the per-tensor checksums are held at 5e-3 wherever the arithmetic is not the reference's own
+STEP_LOSS_TOL = 5e-4
+STEP_STATE_TOL = 5e-3
 
 
 def load(name):
@@ -363,14 +368,13 @@ def test_train_step_reference_order_cpu(oracle_cpu, kind):
 
 @pytest.mark.parametrize("kind", ["fluid_keep", "fluid_init", "action"])
 def test_train_step_cpu(oracle_cpu, kind):
-    """Default MI355X order.  The position losses are continuous in the generator output and
-    are held tightly.  The GAN terms are NOT comparable number-for-number here: an untrained
-    generator emits r near-coincident copies of every input point, so 1e-7 differences in
-    their coordinates flip FPS / ball-query / kNN decisions inside the discriminators
-    (discrete, chaotic); number-for-number parity of those terms is what the
-    reference-order twin above pins, and gradient equality of the two orders on frozen
-    neighbourhoods is pinned by test_both_orders_give_the_same_gradients."""
-    run_step(kind, "cpu", 2e-5, gan_tol=float("inf"), state_tol=float("inf"))
+    """Default MI355X order (first layer before the gather): ALL six losses and the parameters after
+    the step against the reference's.  This works because the fixtures' clips were selected for
+    stability (capture_goldens.step_fixture): on an arbitrary clip an untrained step sits on discrete
+    decisions (FPS picks, ball-query membership, max-pool winners on the generated clouds) that
+    rounding-level differences flip -- the first fixture of this repo read tempo_G_loss = 0.96814 with
+    8 oneDNN threads and 0.94807 with one thread, with oneDNN off, and on every path of this repo."""
+    run_step(kind, "cpu", 2e-5, gan_tol=STEP_LOSS_TOL, state_tol=STEP_STATE_TOL)
 
 
 def test_both_orders_give_the_same_gradients(oracle_cpu):
@@ -426,10 +430,9 @@ def test_both_orders_give_the_same_gradients(oracle_cpu):
 @pytest.mark.gpu
 @pytest.mark.parametrize("kind", ["fluid_keep", "fluid_init", "action"])
 def test_train_step_gpu(kind):
-    """Default MI355X order on the GPU, the reference's draws (cpu_dropout): the position losses
-    are held at 2e-4; the GAN terms and post-step parameters are not comparable number for number
-    in this order (see test_train_step_cpu) and are pinned by the reference-order twin below."""
-    run_step(kind, "cuda", 2e-4, gan_tol=float("inf"), state_tol=float("inf"))
+    """Default MI355X order on the GPU -- the path bench.py times, in fp32 -- with the reference's
+    draws (cpu_dropout): all six losses and the parameters after one SGD step against the goldens."""
+    run_step(kind, "cuda", 2e-4, gan_tol=STEP_LOSS_TOL, state_tol=STEP_STATE_TOL)
 
 
 @pytest.mark.gpu
@@ -441,7 +444,7 @@ def test_train_step_reference_order_gpu(kind):
     draws, ALL six losses and the parameters after one SGD step against the goldens."""
     from tpgan_amd.set_abstraction import reference_order
     with reference_order():
-        run_step(kind, "cuda", 2e-4, gan_tol=GPU_GAN_TOL, state_tol=GPU_STATE_TOL)
+        run_step(kind, "cuda", 2e-4, gan_tol=STEP_LOSS_TOL, state_tol=STEP_STATE_TOL)
 
 
 def test_use_vel_step_runs_on_the_oracle_backend(oracle_cpu):
