@@ -3,7 +3,7 @@ MI355X guide prescribes) into HBM bytes per launch for the kernels of interest.
 
     rocprofv3 --kernel-trace --pmc FETCH_SIZE --output-format csv -d gpurun_out/pmc_fetch -- python3 bench.py ... --eager-body
     rocprofv3 --kernel-trace --pmc WRITE_SIZE --output-format csv -d gpurun_out/pmc_write -- python3 bench.py ... --eager-body
-    python tools/pmc_traffic.py gpurun_out/pmc_fetch gpurun_out/pmc_write > profiles/r01_pmc_traffic.json
+    python tools/pmc_traffic.py gpurun_out/pmc_fetch gpurun_out/pmc_write > profiles/r02_pmc_traffic.json
 
 FETCH_SIZE / WRITE_SIZE are in KiB.  gfx950 correction (MI355X_MICROARCH.md, HBM section): FETCH_SIZE
 reports exactly half of the bytes of a wide (16 B/lane) coalesced streaming read, so it is doubled
@@ -20,6 +20,11 @@ KERNELS = {  # bench op name -> substring of the kernel symbol
     "rowbn_fwd_stats": "rowbn_stats_kernel",
     "rowbn_fwd_apply": "rowbn_apply_kernel",
     "rowbn_fwd_apply_max": "rowbn_apply_max_kernel",
+    "mlp_fwd": "mlp_fwd_kernel",
+    "mlp_dgrad": "mlp_dgrad_kernel",
+    "mlp_wgrad": "mlp_wgrad_kernel",
+    "mlp_bn_bwd_apply": "mlp_bn_bwd_apply_kernel",
+    "frnn_grid": "fg_query_kernel",
     "rowcombine_fwd": "rowcombine_fwd_kernel",
     "rowcombine_bwd": "rowcombine_bwd_",             # thread- and wave-per-row forms
     "ball_query": "ball_query_kernel",
