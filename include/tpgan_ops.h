@@ -205,24 +205,25 @@ int tpg_rowbn_bwd_sums(const void *gy, int dtype_g, const void *x, int dtype_in,
  * (discriminator.py:63-78,140-148,276-282: conv1x1 -> BatchNorm2d -> LeakyReLU per layer) for one
  * layer of the tail, on channels-last bf16 rows:
  *     y = W . lrelu(scale * x + shift)        x (P,Cin) bf16, W (Cout,Cin) f32, y (P,Cout) bf16
- * scale | shift = the INPUT BatchNorm folded per channel (ss_in (nseg,2,Cin), NULL = identity), applied
+ * scale | shift = the INPUT BatchNorm folded per channel (2*Cin floats at ss_in + seg*ss_stride -- the head of
+ * a ci block, below -- NULL = identity), applied
  * together with the LeakyReLU in the MFMA A-operand prologue; bf16 MFMA (v_mfma_f32_16x16x32_bf16),
  * fp32 accumulation, one rounding of y; the epilogue accumulates the batch statistics of y (of the
  * ROUNDED values) and a finalize launch writes mean_out / rstd_out (nseg,Cout), updates
  * running_mean / running_var / num_batches_tracked like nn.BatchNorm (all three may be NULL;
- * mean_shift as in tpg_rowbn_fwd) and, if ss_out != NULL, the folded constants of the OUTPUT
- * BatchNorm (gamma_out, beta_out; NULL = 1 / 0) for the next layer's prologue.
+ * mean_shift as in tpg_rowbn_fwd) and, if ci_out != NULL, the folded constants of the OUTPUT
+ * BatchNorm, ci (nseg,4,Cout) = sc | sh | mu | rs (gamma_out, beta_out; NULL = 1 / 0): its head is the next
+ * layer's ss_in (ss_stride = 4*Cout), the backward kernels read all four.  mean_out = rstd_out = ci_out =
+ * running_mean = NULL: no statistics wanted (a tail without BatchNorm), no finalize launch.
  * nseg segments = nseg calls of the layer on equal consecutive row blocks, each with its own
  * statistics and (w_per_seg != 0) its own weight W[seg] (successive spectral-norm iterates).
  * Supported (Cin,Cout): (64,64) (64,128) (128,64) (128,128) (128,256) (256,128) (256,256);
  * ws: tpg_mlp_workspace_bytes(max(Cin,Cout), nseg) bytes, 16-byte aligned. */
 size_t tpg_mlp_workspace_bytes(int C, int nseg);
-int tpg_mlp_scale_shift(const float *mean, const float *rstd, const float *gamma, const float *beta, int C,
-                        int nseg, float *ss, void *stream);
-int tpg_mlp_fwd(const void *x, long long P, int Cin, int Cout, int nseg, const float *ss_in, float slope_in,
-                const float *W, int w_per_seg, void *y, float eps, float momentum, float *running_mean,
-                float *running_var, long long *num_batches_tracked, const float *mean_shift,
-                const float *gamma_out, const float *beta_out, float *mean_out, float *rstd_out, float *ss_out,
+int tpg_mlp_fwd(const void *x, long long P, int Cin, int Cout, int nseg, const float *ss_in, int ss_stride,
+                float slope_in, const float *W, int w_per_seg, void *y, float eps, float momentum,
+                float *running_mean, float *running_var, long long *num_batches_tracked, const float *mean_shift,
+                const float *gamma_out, const float *beta_out, float *mean_out, float *rstd_out, float *ci_out,
                 void *ws, void *stream);
 
 /* Backward of such a layer, x_in (P,Cin) -> x_out (P,Cout) = W . lrelu(BN_in(x_in)), followed by
@@ -237,7 +238,9 @@ int tpg_mlp_fwd(const void *x, long long P, int Cin, int Cout, int nseg, const f
  * The MFMA operand the kernels build is the centred d = dx_out - e (one fma per element); e enters as a rank-one
  * term (e^T W per input channel in tpg_mlp_dgrad's epilogue, e (x) sum_rows a_in in tpg_mlp_wgrad).
  * tpg_mlp_dgrad: g_in (P,Cin) bf16 = (dx_out . W) * lrelu'(z_in) and BN_in's backward sums:
- *   c12_in (nseg,2,Cin), dgamma_in / dbeta_in (Cin, summed over segments, may be NULL).
+ *   c12_in (nseg,2,Cin), dgamma_in / dbeta_in (Cin, summed over segments) and cb_in (nseg,4,Cin) = the cb of
+ *   BN_in for the NEXT tpg_mlp_dgrad / tpg_mlp_wgrad one layer down -- each may be NULL, all NULL = BN_in is
+ *   the identity (no finalize launch).
  *   ci_in (nseg,4,Cin) = sc | sh | mu | rs of BN_in (tpg_mlp_consts).  ws: tpg_mlp_workspace_bytes.
  * tpg_mlp_wgrad: dW (nseg,Cout,Cin) f32 = dx_out^T . lrelu(BN_in(x_in)), both operands rebuilt from the
  *   saved rows, staged in LDS and read transposed (ds_read_b64_tr_b16); per-workgroup fp32 slabs summed
@@ -250,7 +253,7 @@ int tpg_mlp_max_prep(const void *gout, const void *y, const float *cb_out, float
 int tpg_mlp_dgrad(const void *x_out, const void *g_out, const uint8_t *arg, int K, const float *cb_out,
                   const void *x_in, const float *ci_in, float slope_in, const float *W,
                   int w_per_seg, long long P, int Cin, int Cout, int nseg, int mode, void *g_in, float *c12_in,
-                  float *dgamma_in, float *dbeta_in, void *ws, void *stream);
+                  float *dgamma_in, float *dbeta_in, float *cb_in, void *ws, void *stream);
 size_t tpg_mlp_wgrad_workspace_bytes(long long P, int Cin, int Cout, int nseg);
 int tpg_mlp_wgrad(const void *x_out, const void *g_out, const uint8_t *arg, int K, const float *cb_out,
                   const void *x_in, const float *ci_in, float slope_in, long long P, int Cin,

@@ -44,13 +44,12 @@ SIGNATURES = {
     "tpg_spectral_norm_multi_fwd": [_P, _I, _I, _P, _I, _F, _P],
     "tpg_spectral_norm_multi_bwd": [_P, _I, _I, _P, _P, _P, _P, _P],
     "tpg_rowbn_bwd_sums": [_P, _I, _P, _I, _P, _P, _I, _L, _I, _I, _I, _P, _P, _P, _P, _F, _P, _P, _P, _P, _I, _P],
-    "tpg_mlp_scale_shift": [_P, _P, _P, _P, _I, _I, _P, _P],
     "tpg_mlp_consts": [_P, _P, _P, _P, _P, _I, _I, _P, _P, _P],
     "tpg_mlp_max_prep": [_P, _P, _P, _F, _L, _I, _I, _P, _P],
-    "tpg_mlp_dgrad": [_P, _P, _P, _I, _P, _P, _P, _F, _P, _I, _L, _I, _I, _I, _I, _P, _P, _P, _P, _P, _P],
+    "tpg_mlp_dgrad": [_P, _P, _P, _I, _P, _P, _P, _F, _P, _I, _L, _I, _I, _I, _I, _P, _P, _P, _P, _P, _P, _P],
     "tpg_mlp_wgrad": [_P, _P, _P, _I, _P, _P, _P, _F, _L, _I, _I, _I, _I, _P, _P, _P],
     "tpg_mlp_bn_bwd_apply": [_P, _P, _P, _P, _L, _I, _I, _P, _P],
-    "tpg_mlp_fwd": [_P, _L, _I, _I, _I, _P, _F, _P, _I, _P, _F, _F, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P],
+    "tpg_mlp_fwd": [_P, _L, _I, _I, _I, _P, _I, _F, _P, _I, _P, _F, _F, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P],
 }
 SIZE_GETTERS = ("tpg_rowbn_workspace_bytes", "tpg_mlp_workspace_bytes")
 OTHER_GETTERS = ("tpg_spectral_norm_multi_stride", "tpg_spectral_norm_multi_bwd_scratch",

@@ -43,10 +43,12 @@ __global__ __launch_bounds__(BLOCK) void fps_kernel(const float *__restrict__ xy
                                                     const int32_t *__restrict__ start, int skip_origin) {
     extern __shared__ __attribute__((aligned(16))) float fps_smem[];
     constexpr int NW = BLOCK / 64;
-    // layout: [2][16] (value,index) slots (256 B), then a copy of the cloud (USE_LDS): xyz of a
-    // point side by side, so the winner's coordinates are one address and three offsets
+    // layout: [2][16] (value,index) slots (256 B), [2][16] xyz of each wave's winner (768 B: clouds too
+    // large for an LDS copy), then a copy of the cloud (USE_LDS): xyz of a point side by side, so the
+    // winner's coordinates are one address and three offsets
     int2 *slots = reinterpret_cast<int2 *>(fps_smem);
-    float *sp = fps_smem + 64;
+    float *wxyz = fps_smem + 64;          // [2][16][4]
+    float *sp = fps_smem + 64 + 128;
 
     const int tid = threadIdx.x;
     const int lane = tid & 63;
@@ -71,12 +73,12 @@ __global__ __launch_bounds__(BLOCK) void fps_kernel(const float *__restrict__ xy
     }
     int old = start ? tpg_clamp_idx(start[blockIdx.x], N) : 0;       // pointnet2: always point 0
     if (tid == 0) out[0] = old;
+    // the first pick's coordinates (clouds without an LDS copy: from memory, once)
+    float ox = x[(size_t)old * 3], oy = x[(size_t)old * 3 + 1], oz = x[(size_t)old * 3 + 2];
     if (NW > 1 || USE_LDS) __syncthreads();
 
     for (int j = 1; j < m; ++j) {
-        float ox, oy, oz;
         if (USE_LDS) { ox = sp[3 * old]; oy = sp[3 * old + 1]; oz = sp[3 * old + 2]; }
-        else { ox = x[(size_t)old * 3]; oy = x[(size_t)old * 3 + 1]; oz = x[(size_t)old * 3 + 2]; }
 
         int best = __float_as_int(-1.0f);
         int besti = 0;
@@ -94,16 +96,42 @@ __global__ __launch_bounds__(BLOCK) void fps_kernel(const float *__restrict__ xy
         // the value's max, then the index of the FIRST lane that attains it (lower lane <=> lower
         // indices): the mask is never empty, the maximum is somebody's value
         int mx = tpg_wave_max_i32_rows(best);
-        int bi = __builtin_amdgcn_readlane(besti, __builtin_ctzll(__ballot(best == mx)));
+        const int src = __builtin_ctzll(__ballot(best == mx));
+        int bi = __builtin_amdgcn_readlane(besti, src);
+        if constexpr (!USE_LDS) {
+            // no LDS copy of the cloud (N > 12288): the winning lane hands on its point's coordinates
+            // itself -- a round trip to L2 for 12 bytes cost 3 of the 3.5 us of a round at 16384 points
+            if (lane == src) {
+                const int bt = bi - tid * PPT;
+                float sx = px[0], sy = py[0], sz = pz[0];
+#pragma unroll
+                for (int t = 1; t < PPT; ++t) {
+                    const bool hit = bt == t;
+                    sx = hit ? px[t] : sx; sy = hit ? py[t] : sy; sz = hit ? pz[t] : sz;
+                }
+                float *w = wxyz + ((j & 1) * 16 + wave) * 4;
+                w[0] = sx; w[1] = sy; w[2] = sz;
+            }
+        }
+        int win = wave;
         if constexpr (NW > 1) {
             int2 *slot = slots + (j & 1) * 16;
             if (lane == 0) slot[wave] = make_int2(mx, bi);
             __syncthreads();
             const int2 sv = lane < NW ? slot[lane] : make_int2((int)0x80000000, 0);
             mx = tpg_row16_max_i32(sv.x);         // every slot value is >= bits(-1.0f) > INT_MIN
-            bi = __builtin_amdgcn_readlane(sv.y, __builtin_ctzll(__ballot(sv.x == mx)));
+            win = __builtin_ctzll(__ballot(sv.x == mx));
+            bi = __builtin_amdgcn_readlane(sv.y, win);
         }
         old = mx >= 0 ? bi : 0;                   // mx < 0 <=> no eligible point at all
+        if constexpr (!USE_LDS) {
+            if (mx >= 0) {
+                const float *w = wxyz + ((j & 1) * 16 + win) * 4;     // (single wave: its own LDS writes, in order)
+                ox = w[0]; oy = w[1]; oz = w[2];
+            } else {
+                ox = x[0]; oy = x[1]; oz = x[2];
+            }
+        }
         if (tid == 0) out[j] = old;
     }
 }
@@ -158,21 +186,21 @@ template <int BLOCK, int PPT>
 void fps_go(const float *xyz, int B, int N, int m, int32_t *idx, const int32_t *start, int skip_origin,
             hipStream_t st) {
     int use_lds = N <= FPS_LDS_POINTS;
-    size_t smem = 256 + (use_lds ? sizeof(float) * 3 * (size_t)N : 0);
+    size_t smem = 256 + 512 + (use_lds ? sizeof(float) * 3 * (size_t)N : 0);
     if (smem > 48 * 1024) {
         // opt in to > 48 KiB of dynamic LDS once per instantiation (not a stream operation, so
         // it must not happen inside a captured launch sequence): request the maximum this
         // instantiation can ever need.
         static int granted = -1;
         if (granted < 0) {
-            const int want = 256 + (int)sizeof(float) * 3 * FPS_LDS_POINTS;
+            const int want = 256 + 512 + (int)sizeof(float) * 3 * FPS_LDS_POINTS;
             granted = hipFuncSetAttribute(reinterpret_cast<const void *>(&fps_kernel<BLOCK, PPT, true>),
                                           hipFuncAttributeMaxDynamicSharedMemorySize, want) == hipSuccess;
             if (!granted) (void)hipGetLastError();
         }
         if (!granted) {
             use_lds = 0;  // read the selected point from L2 instead
-            smem = 256;
+            smem = 256 + 512;
         }
     }
     if (use_lds)

@@ -60,11 +60,11 @@ template <int COUT> __device__ __forceinline__ int w_lds_row(int n) {
 
 // ------------------------------------------------------------------------------------ forward
 // grid (G, nseg); a workgroup walks tiles blockIdx.x, blockIdx.x + G, ... of its segment.
-// x (nseg*P, CIN) bf16; ss (nseg, 2, CIN) f32 = BatchNorm scale | shift of the INPUT (NULL: none);
+// x (nseg*P, CIN) bf16; ss = BatchNorm scale | shift of the INPUT, 2*CIN floats at ss + seg*ss_stride (NULL: none);
 // W (nseg or 1, COUT, CIN) f32; y (nseg*P, COUT) bf16; part (nseg, G, 3, COUT) f32 = mean | M2 | n.
 template <int CIN, int COUT, int STRIPS>
 __global__ __launch_bounds__(ML_THREADS, 2) void mlp_fwd_kernel(
-    const __hip_bfloat16 *__restrict__ x, long long P, const float *__restrict__ ss, float slope,
+    const __hip_bfloat16 *__restrict__ x, long long P, const float *__restrict__ ss, int ss_stride, float slope,
     const float *__restrict__ W, int w_per_seg, __hip_bfloat16 *__restrict__ y, float *__restrict__ part) {
     constexpr int T = COUT / 16;            // column tiles = consecutive channels per lane
     constexpr int KS = CIN / 32;            // k-steps
@@ -91,7 +91,7 @@ __global__ __launch_bounds__(ML_THREADS, 2) void mlp_fwd_kernel(
             *reinterpret_cast<uint2 *>(wl + (size_t)w_lds_row<COUT>(n) * WROW + k) = p;
         }
         for (int c = tid; c < 2 * CIN; c += ML_THREADS)
-            cst[c] = ss ? ss[(size_t)seg * 2 * CIN + c] : (c < CIN ? 1.0f : 0.0f);
+            cst[c] = ss ? ss[(size_t)seg * ss_stride + c] : (c < CIN ? 1.0f : 0.0f);
     }
     __syncthreads();
     // statistics of the lane's T output channels li*T + t over the rows it sees
@@ -254,7 +254,7 @@ __global__ __launch_bounds__(ML_THREADS) void mlp_stats_finalize_kernel(
     const float *__restrict__ part, int G, int C, int nseg, float eps, float momentum,
     float *__restrict__ running_mean, float *__restrict__ running_var, long long *__restrict__ num_batches_tracked,
     const float *__restrict__ mean_shift, const float *__restrict__ gamma, const float *__restrict__ beta,
-    float *__restrict__ mean, float *__restrict__ rstd, float *__restrict__ ss_next) {
+    float *__restrict__ mean, float *__restrict__ rstd, float *__restrict__ ci_out) {
     __shared__ double red[3][MF_LANES][MF_CH];
     const int cl = threadIdx.x % MF_CH, gl = threadIdx.x / MF_CH;
     const int c = blockIdx.x * MF_CH + cl;
@@ -300,12 +300,12 @@ __global__ __launch_bounds__(ML_THREADS) void mlp_stats_finalize_kernel(
             double var = N > 0.0 ? red[2][0][cl] / N : 0.0;          // biased
             var = var < 0.0 ? 0.0 : var;
             const float mu = (float)m, rs = (float)(1.0 / sqrt(var + (double)eps));
-            mean[(size_t)seg * C + c] = mu;
-            rstd[(size_t)seg * C + c] = rs;
-            if (ss_next) {
+            if (mean) mean[(size_t)seg * C + c] = mu;
+            if (rstd) rstd[(size_t)seg * C + c] = rs;
+            if (ci_out) {
                 const float a = (gamma ? gamma[c] : 1.0f) * rs;
-                ss_next[((size_t)seg * 2 + 0) * C + c] = a;
-                ss_next[((size_t)seg * 2 + 1) * C + c] = (beta ? beta[c] : 0.0f) - mu * a;
+                float *o = ci_out + (size_t)seg * 4 * C + c;
+                o[0] = a; o[C] = (beta ? beta[c] : 0.0f) - mu * a; o[2 * C] = mu; o[3 * C] = rs;
             }
             if (running_mean) {
                 const double unbiased = N > 1.0 ? var * N / (N - 1.0) : var;
@@ -316,18 +316,6 @@ __global__ __launch_bounds__(ML_THREADS) void mlp_stats_finalize_kernel(
         }
         __syncthreads();
     }
-}
-
-// scale | shift of a BatchNorm from its statistics: ss (nseg, 2, C)
-__global__ void mlp_scale_shift_kernel(const float *__restrict__ mean, const float *__restrict__ rstd,
-                                       const float *__restrict__ gamma, const float *__restrict__ beta, int C,
-                                       int nseg, float *__restrict__ ss) {
-    const int i = blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= nseg * C) return;
-    const int seg = i / C, c = i - seg * C;
-    const float a = (gamma ? gamma[c] : 1.0f) * (rstd ? rstd[i] : 1.0f);
-    ss[((size_t)seg * 2 + 0) * C + c] = a;
-    ss[((size_t)seg * 2 + 1) * C + c] = (beta ? beta[c] : 0.0f) - (mean ? mean[i] : 0.0f) * a;
 }
 
 // ------------------------------------------------------------------------------------ backward
@@ -612,12 +600,14 @@ __global__ __launch_bounds__(ML_THREADS, OCC) void mlp_dgrad_kernel(
 
 // partial sums of the data-gradient kernel (sum g | sum g (x - mu)) -> c12 (nseg,2,C) = (sum g / P |
 // rstd * sum g (x - mu) / P) per segment, dgamma = sum over segments of sum g xhat, dbeta = of sum g
-// (both optional); rstd of segment s at rstd + s*rstd_stride; grid ceil(C/4)
+// (both optional); rstd of segment s at rstd + s*rstd_stride; cb (nseg,4,C), optional: see below; grid ceil(C/4)
 __global__ __launch_bounds__(ML_THREADS) void mlp_bwd_finalize_kernel(const float *__restrict__ part, int G, long long P,
                                                                       int C, int nseg, const float *__restrict__ rstd,
                                                                       int rstd_stride, float *__restrict__ c12,
                                                                       float *__restrict__ dgamma,
-                                                                      float *__restrict__ dbeta) {
+                                                                      float *__restrict__ dbeta,
+                                                                      const float *__restrict__ ci,
+                                                                      float *__restrict__ cb) {
     __shared__ double red[2][MF_LANES][MF_CH];
     const int cl = threadIdx.x % MF_CH, gl = threadIdx.x / MF_CH;
     const int c = blockIdx.x * MF_CH + cl;
@@ -644,8 +634,19 @@ __global__ __launch_bounds__(ML_THREADS) void mlp_bwd_finalize_kernel(const floa
             const double s = red[0][0][cl], sx = red[1][0][cl] * (double)rstd[(size_t)seg * rstd_stride + c];
             ts += s;
             tsx += sx;
-            c12[((size_t)seg * 2 + 0) * C + c] = (float)(s / (double)P);
-            c12[((size_t)seg * 2 + 1) * C + c] = (float)(sx / (double)P);
+            const float c1 = (float)(s / (double)P), c2 = (float)(sx / (double)P);
+            if (c12) {
+                c12[((size_t)seg * 2 + 0) * C + c] = c1;
+                c12[((size_t)seg * 2 + 1) * C + c] = c2;
+            }
+            if (cb) {
+                // the folded constants of THIS BatchNorm's backward, for the kernels one layer down:
+                // a | f*mu | e | f  (ci = sc | sh | mu | rs of the same BatchNorm)
+                const float *ip = ci + (size_t)seg * 4 * C + c;
+                const float a = ip[0], mu = ip[2 * C], f = a * ip[3 * C] * c2;
+                float *o = cb + (size_t)seg * 4 * C + c;
+                o[0] = a; o[C] = f * mu; o[2 * C] = -a * c1; o[3 * C] = f;
+            }
         }
         __syncthreads();
     }
@@ -947,8 +948,8 @@ int fwd_blocks(long long P, int bm, int nseg) {
 }
 
 template <int CIN, int COUT>
-int fwd_launch(const void *x, long long P, int nseg, const float *ss, float slope, const float *W, int w_per_seg,
-               void *y, float *part, int *G_out, hipStream_t st) {
+int fwd_launch(const void *x, long long P, int nseg, const float *ss, int ss_stride, float slope, const float *W,
+               int w_per_seg, void *y, float *part, int *G_out, hipStream_t st) {
     constexpr int STRIPS = fwd_strips<CIN, COUT>();
     constexpr int BM = ML_WAVES * STRIPS * 16;
     constexpr size_t smem = fwd_smem<CIN, COUT>();
@@ -965,7 +966,7 @@ int fwd_launch(const void *x, long long P, int nseg, const float *ss, float slop
     const int G = fwd_blocks(P, BM, nseg);
     *G_out = G;
     hipLaunchKernelGGL(kern, dim3(G, nseg), dim3(ML_THREADS), smem, st, static_cast<const __hip_bfloat16 *>(x), P, ss,
-                       slope, W, w_per_seg, static_cast<__hip_bfloat16 *>(y), part);
+                       ss_stride, slope, W, w_per_seg, static_cast<__hip_bfloat16 *>(y), part);
     return TPG_OK;
 }
 
@@ -1043,6 +1044,8 @@ bool ml_shape_ok(int Cin, int Cout) {
 
 }  // namespace
 
+#define TPG_ML_SHAPES(X) X(64, 64) X(64, 128) X(128, 64) X(128, 128) X(128, 256) X(256, 128) X(256, 256)
+
 extern "C" size_t tpg_mlp_workspace_bytes(int C, int nseg) {
     if (nseg < 1) nseg = 1;
     // per-workgroup partials (mean | M2 | n) of the forward, (sum g | sum g xhat) of the backward,
@@ -1050,23 +1053,13 @@ extern "C" size_t tpg_mlp_workspace_bytes(int C, int nseg) {
     return sizeof(float) * ((size_t)nseg * ML_MAX_BLOCKS * 3 * C + 64);
 }
 
-extern "C" int tpg_mlp_scale_shift(const float *mean, const float *rstd, const float *gamma, const float *beta,
-                                   int C, int nseg, float *ss, void *stream) {
-    if (C <= 0 || nseg < 1 || !ss || ((mean == nullptr) != (rstd == nullptr))) return TPG_ERR_ARG;
-    const int n = nseg * C;
-    hipLaunchKernelGGL(mlp_scale_shift_kernel, dim3((n + 255) / 256), dim3(256), 0, tpg_stream(stream), mean, rstd,
-                       gamma, beta, C, nseg, ss);
-    TPG_RETURN_IF_LAUNCH_FAILED();
-    return TPG_OK;
-}
-
-extern "C" int tpg_mlp_fwd(const void *x, long long P, int Cin, int Cout, int nseg, const float *ss_in,
+extern "C" int tpg_mlp_fwd(const void *x, long long P, int Cin, int Cout, int nseg, const float *ss_in, int ss_stride,
                            float slope_in, const float *W, int w_per_seg, void *y, float eps, float momentum,
                            float *running_mean, float *running_var, long long *num_batches_tracked,
                            const float *mean_shift, const float *gamma_out, const float *beta_out, float *mean_out,
-                           float *rstd_out, float *ss_out, void *ws, void *stream) {
+                           float *rstd_out, float *ci_out, void *ws, void *stream) {
     if (P <= 0 || nseg < 1 || nseg > 65535 || P % nseg) return TPG_ERR_ARG;
-    if (!x || !W || !y || !ws || !mean_out || !rstd_out) return TPG_ERR_ARG;
+    if (!x || !W || !y || !ws || (ss_in && ss_stride < 2 * Cin)) return TPG_ERR_ARG;
     if ((reinterpret_cast<uintptr_t>(x) | reinterpret_cast<uintptr_t>(y) | reinterpret_cast<uintptr_t>(W) |
          reinterpret_cast<uintptr_t>(ws)) & 15)
         return TPG_ERR_UNSUPPORTED;
@@ -1075,19 +1068,16 @@ extern "C" int tpg_mlp_fwd(const void *x, long long P, int Cin, int Cout, int ns
     float *part = static_cast<float *>(ws);
     int G = 0, rc = TPG_ERR_UNSUPPORTED;
 #define TPG_ML_FWD(CI, CO)                                                                                 \
-    if (Cin == CI && Cout == CO) rc = fwd_launch<CI, CO>(x, P, nseg, ss_in, slope_in, W, w_per_seg, y, part, &G, st)
-    TPG_ML_FWD(64, 64);
-    TPG_ML_FWD(64, 128);
-    TPG_ML_FWD(128, 64);
-    TPG_ML_FWD(128, 128);
-    TPG_ML_FWD(128, 256);
-    TPG_ML_FWD(256, 128);
-    TPG_ML_FWD(256, 256);
+    if (Cin == CI && Cout == CO)                                                                           \
+        rc = fwd_launch<CI, CO>(x, P, nseg, ss_in, ss_stride, slope_in, W, w_per_seg, y, part, &G, st);
+    TPG_ML_SHAPES(TPG_ML_FWD)
 #undef TPG_ML_FWD
     if (rc) return rc;
-    hipLaunchKernelGGL(mlp_stats_finalize_kernel, dim3((Cout + MF_CH - 1) / MF_CH), dim3(ML_THREADS), 0, st, part, G,
-                       Cout, nseg, eps, momentum, running_mean, running_var, num_batches_tracked, mean_shift, gamma_out,
-                       beta_out, mean_out, rstd_out, ss_out);
+    // no statistics wanted (a tail without BatchNorm: the generator's EdgeConv MLPs): no finalize launch
+    if (mean_out || rstd_out || ci_out || running_mean)
+        hipLaunchKernelGGL(mlp_stats_finalize_kernel, dim3((Cout + MF_CH - 1) / MF_CH), dim3(ML_THREADS), 0, st, part, G,
+                           Cout, nseg, eps, momentum, running_mean, running_var, num_batches_tracked, mean_shift,
+                           gamma_out, beta_out, mean_out, rstd_out, ci_out);
     TPG_RETURN_IF_LAUNCH_FAILED();
     return TPG_OK;
 }
@@ -1101,8 +1091,6 @@ extern "C" int tpg_mlp_consts(const float *mean, const float *rstd, const float 
     TPG_RETURN_IF_LAUNCH_FAILED();
     return TPG_OK;
 }
-
-#define TPG_ML_SHAPES(X) X(64, 64) X(64, 128) X(128, 64) X(128, 128) X(128, 256) X(256, 128) X(256, 256)
 
 extern "C" int tpg_mlp_max_prep(const void *gout, const void *y, const float *cb_out, float slope_out, long long rows,
                                 int C, int nseg, void *ag, void *stream) {
@@ -1124,9 +1112,9 @@ extern "C" int tpg_mlp_max_prep(const void *gout, const void *y, const float *cb
 extern "C" int tpg_mlp_dgrad(const void *x_out, const void *g_out, const uint8_t *arg, int K, const float *cb_out,
                              const void *x_in, const float *ci_in, float slope_in, const float *W,
                              int w_per_seg, long long P, int Cin, int Cout, int nseg, int mode, void *g_in,
-                             float *c12_in, float *dgamma_in, float *dbeta_in, void *ws, void *stream) {
+                             float *c12_in, float *dgamma_in, float *dbeta_in, float *cb_in, void *ws, void *stream) {
     if (P <= 0 || nseg < 1 || nseg > 65535 || P % nseg || (mode != MODE_DENSE && mode != MODE_MAX)) return TPG_ERR_ARG;
-    if (!x_out || !g_out || !cb_out || !x_in || !ci_in || !W || !g_in || !c12_in || !ws) return TPG_ERR_ARG;
+    if (!x_out || !g_out || !cb_out || !x_in || !ci_in || !W || !g_in || !ws) return TPG_ERR_ARG;
     P /= nseg;
     if (mode == MODE_MAX && (!arg || K <= 0 || K > 256 || P % K)) return TPG_ERR_ARG;
     if (P >= 0x7fffffffLL || !ml_shape_ok(Cin, Cout)) return TPG_ERR_UNSUPPORTED;
@@ -1146,9 +1134,11 @@ extern "C" int tpg_mlp_dgrad(const void *x_out, const void *g_out, const uint8_t
     TPG_ML_SHAPES(TPG_ML_DG)
 #undef TPG_ML_DG
     if (rc) return rc;
-    // (ci_in = sc | sh | mu | rs per segment: the finalize reads rs with stride 4*Cin)
-    hipLaunchKernelGGL(mlp_bwd_finalize_kernel, dim3((Cin + MF_CH - 1) / MF_CH), dim3(ML_THREADS), 0, st, part, G, P, Cin,
-                       nseg, ci_in + 3 * Cin, 4 * Cin, c12_in, dgamma_in, dbeta_in);
+    // (ci_in = sc | sh | mu | rs per segment: the finalize reads rs with stride 4*Cin); nothing wanted
+    // (an input without BatchNorm: the generator's EdgeConv MLPs): no finalize launch
+    if (c12_in || dgamma_in || dbeta_in || cb_in)
+        hipLaunchKernelGGL(mlp_bwd_finalize_kernel, dim3((Cin + MF_CH - 1) / MF_CH), dim3(ML_THREADS), 0, st, part, G, P,
+                           Cin, nseg, ci_in + 3 * Cin, 4 * Cin, c12_in, dgamma_in, dbeta_in, ci_in, cb_in);
     TPG_RETURN_IF_LAUNCH_FAILED();
     return TPG_OK;
 }

@@ -42,6 +42,10 @@ def rows_first():
     return _ROWS_FIRST[0]
 
 
+# the EdgeConv MLPs through ops.mlp_tail_plain (off: hipBLASLt GEMMs + separate activations, for A/B runs)
+FUSED_EDGE_TAILS = [True]
+
+
 @contextlib.contextmanager
 def reference_order(enabled=True):
     """Run generator and discriminators in the reference's order of operations."""
@@ -402,6 +406,9 @@ class EdgeConv(nn.Module):
         if self.mlp_layer:
             mods = list(self.mlp)
             C_out = mods[-2].out_channels if isinstance(mods[-2], nn.Conv2d) else 0
+            fused = self._fused_tail(mods, h)
+            if fused is not None:
+                return fused
             if (self.aggregate == "max" and isinstance(mods[-1], nn.LeakyReLU) and C_out % 8 == 0
                     and 0 < C_out <= 1024 and h.shape[2] <= 256):
                 # last [LeakyReLU -> max over k] fused into one pass (ops.row_act_max)
@@ -413,6 +420,28 @@ class EdgeConv(nn.Module):
         if self.aggregate in ("sum", "mean"):                           # linear commutes with sum
             return rows_seq(self.mlp, _agg(self.aggregate, h, 2))
         return _agg(self.aggregate, rows_seq(self.mlp, h), 2)
+
+    def _fused_tail(self, mods, h):
+        """[conv, LeakyReLU]* -> max over the k neighbours of h (B,N,k,H) on the fused MFMA kernels
+        (ops.mlp_tail_plain, csrc/mlp_fused.hip) where they take the shapes: bf16 rows on the GPU, supported
+        channel pairs, bare convs.  -> (B,N,C_out) or None."""
+        if not (FUSED_EDGE_TAILS[0] and self.aggregate == "max" and h.is_cuda and h.dtype == torch.bfloat16):
+            return None
+        convs, slopes = [], [1.0]
+        for i in range(0, len(mods), 2):
+            conv, act = mods[i], mods[i + 1] if i + 1 < len(mods) else None
+            if not (isinstance(conv, nn.Conv2d) and conv.bias is None and isinstance(act, nn.LeakyReLU)
+                    and 0.0 <= act.negative_slope <= 1.0):
+                return None
+            convs.append(conv)
+            slopes.append(float(act.negative_slope))
+        B, N, k, H = h.shape
+        chans = [H] + [c.out_channels for c in convs]
+        if not ops.mlp_tail_supported(h, chans, k) or any(c.in_channels != a for c, a in zip(convs, chans[:-1])):
+            return None
+        Ws = [c.weight.view(c.out_channels, -1).float() for c in convs]
+        out = ops.mlp_tail_plain(h.view(B * N * k, H), Ws, slopes, k)
+        return out.view(B, N, chans[-1])
 
     # ---- reference order, any norm -------------------------------------------------------
     def _forward_planes(self, feat, pos=None):

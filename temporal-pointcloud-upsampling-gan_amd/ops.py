@@ -372,30 +372,25 @@ class HipBackend:
             self._ws[key] = ws
         return ws
 
-    def mlp_scale_shift(self, mean, rstd, gamma, beta, C_, nseg, like):
-        ss = torch.empty((nseg, 2, C_), dtype=torch.float32, device=like.device)
-        self._call("tpg_mlp_scale_shift", "mlp_scale_shift", 16 * nseg * C_, like, _ptr(mean), _ptr(rstd),
-                   _ptr(gamma), _ptr(beta), C_, nseg, _ptr(ss))
-        return ss
-
-    def mlp_fwd(self, x, ss_in, slope_in, W, nseg, eps, momentum, running_mean, running_var,
-                num_batches_tracked, mean_shift, gamma_out, beta_out):
-        """y = W . lrelu(ss_in[0] * x + ss_in[1]) on bf16 rows + batch statistics of y.
-        -> y (P,Cout) bf16, mean (nseg,Cout), rstd (nseg,Cout), ss_out (nseg,2,Cout)."""
+    def mlp_fwd(self, x, ss_in, slope_in, W, nseg, eps=0.0, momentum=0.0, running_mean=None, running_var=None,
+                num_batches_tracked=None, mean_shift=None, gamma_out=None, beta_out=None, stats=True):
+        """y = W . lrelu(sc * x + sh) on bf16 rows [+ batch statistics of y].
+        ss_in: None (identity) or a tensor whose per-segment blocks START with sc | sh of the input
+        BatchNorm -- (nseg,2,Cin) or a ci block (nseg,4,Cin).
+        -> y (P,Cout) bf16, ci_out (nseg,4,Cout) = sc | sh | mu | rs of the OUTPUT BatchNorm (None if not stats)."""
         P, Cin = x.shape
         w_per_seg = int(W.dim() == 3 and W.shape[0] == nseg and nseg > 1)
         Cout = W.shape[-2]
         y = torch.empty((P, Cout), dtype=torch.bfloat16, device=x.device)
-        mean = torch.empty((nseg, Cout), dtype=torch.float32, device=x.device)
-        rstd = torch.empty((nseg, Cout), dtype=torch.float32, device=x.device)
-        ss_out = torch.empty((nseg, 2, Cout), dtype=torch.float32, device=x.device)
+        ci_out = torch.empty((nseg, 4, Cout), dtype=torch.float32, device=x.device) if stats else None
         ws = self._mlp_ws(x, max(Cin, Cout), nseg)
+        ss_stride = 0 if ss_in is None else ss_in.shape[1] * ss_in.shape[2]
         self._call("tpg_mlp_fwd", "mlp_fwd", 2 * P * (Cin + Cout), x,
-                   _ptr(x), P, Cin, Cout, nseg, _ptr(ss_in), float(slope_in), _ptr(W), w_per_seg, _ptr(y), float(eps),
-                   float(momentum), _ptr(running_mean), _ptr(running_var), _ptr(num_batches_tracked), _ptr(mean_shift),
-                   _ptr(gamma_out), _ptr(beta_out), _ptr(mean), _ptr(rstd), _ptr(ss_out), _ptr(ws),
+                   _ptr(x), P, Cin, Cout, nseg, _ptr(ss_in), ss_stride, float(slope_in), _ptr(W), w_per_seg, _ptr(y),
+                   float(eps), float(momentum), _ptr(running_mean), _ptr(running_var), _ptr(num_batches_tracked),
+                   _ptr(mean_shift), _ptr(gamma_out), _ptr(beta_out), None, None, _ptr(ci_out), _ptr(ws),
                    flops=2 * P * Cin * Cout)
-        return y, mean, rstd, ss_out
+        return y, ci_out
 
     def rowbn_stats(self, x, eps, momentum, running_mean, running_var, num_batches_tracked, nseg, mean_shift):
         """Training-mode batch statistics of x (P,C) alone (the reduction half of rowbn_fwd): mean, rstd
@@ -455,22 +450,25 @@ class HipBackend:
                    float(slope_out), rows, Cc, nseg, _ptr(ag))
         return ag
 
-    def mlp_dgrad(self, x_out, g_out, arg, K, cb_out, x_in, ci_in, slope_in, W, nseg, need_affine):
-        """-> g_in (P,Cin) bf16, c12_in (nseg,2,Cin), dgamma_in, dbeta_in."""
+    def mlp_dgrad(self, x_out, g_out, arg, K, cb_out, x_in, ci_in, slope_in, W, nseg, need_affine, sums=True):
+        """-> g_in (P,Cin) bf16, c12_in (nseg,2,Cin), cb_in (nseg,4,Cin), dgamma_in, dbeta_in
+        (sums=False: BN_in is the identity -- nothing but g_in)."""
         P, Cout = x_out.shape
         Cin = x_in.shape[1]
         mode = 1 if arg is not None else 0
         w_per_seg = int(W.dim() == 3 and W.shape[0] == nseg and nseg > 1)
-        g_in = torch.empty((P, Cin), dtype=torch.bfloat16, device=x_out.device)
-        c12 = torch.empty((nseg, 2, Cin), dtype=torch.float32, device=x_out.device)
-        dgamma = torch.empty(Cin, dtype=torch.float32, device=x_out.device) if need_affine else None
-        dbeta = torch.empty(Cin, dtype=torch.float32, device=x_out.device) if need_affine else None
+        dev = x_out.device
+        g_in = torch.empty((P, Cin), dtype=torch.bfloat16, device=dev)
+        c12 = torch.empty((nseg, 2, Cin), dtype=torch.float32, device=dev) if sums else None
+        cb_in = torch.empty((nseg, 4, Cin), dtype=torch.float32, device=dev) if sums else None
+        dgamma = torch.empty(Cin, dtype=torch.float32, device=dev) if (need_affine and sums) else None
+        dbeta = torch.empty(Cin, dtype=torch.float32, device=dev) if (need_affine and sums) else None
         ws = self._mlp_ws(x_out, max(Cin, Cout), nseg)
         self._call("tpg_mlp_dgrad", "mlp_dgrad", 2 * P * (Cout + 2 * Cin) + (0 if mode else 2 * P * Cout), x_out,
                    _ptr(x_out), _ptr(g_out), _ptr(arg), int(K), _ptr(cb_out), _ptr(x_in), _ptr(ci_in),
                    float(slope_in), _ptr(W), w_per_seg, P, Cin, Cout, nseg, mode, _ptr(g_in), _ptr(c12), _ptr(dgamma),
-                   _ptr(dbeta), _ptr(ws), flops=2 * P * Cin * Cout)
-        return g_in, c12, dgamma, dbeta
+                   _ptr(dbeta), _ptr(cb_in), _ptr(ws), flops=2 * P * Cin * Cout)
+        return g_in, c12, cb_in, dgamma, dbeta
 
     def mlp_wgrad(self, x_out, g_out, arg, K, cb_out, x_in, ci_in, slope_in, nseg):
         """-> dW (nseg,Cout,Cin) f32."""
@@ -1046,22 +1044,19 @@ class _MlpTail(torch.autograd.Function):
         gam = [tensors[0]] + [tensors[3 * l + 3] for l in range(L)]
         bet = [tensors[1]] + [tensors[3 * l + 4] for l in range(L)]
         Ws = [tensors[3 * l + 2] for l in range(L)]
-        xs, means, rstds = [x0], [], []
+        xs, cis = [x0], []
         rm, rv, nbt = states[0]
         m0, r0 = be.rowbn_stats(x0, eps[0], moms[0], rm, rv, nbt, nseg, shifts[0])
-        means.append(m0)
-        rstds.append(r0)
-        ss = be.mlp_scale_shift(m0, r0, gam[0], bet[0], x0.shape[1], nseg, x0)
+        cis.append(be.mlp_consts(m0, r0, gam[0], bet[0], None, True, False)[0])       # sc | sh | mu | rs
         for l in range(L):
             rm, rv, nbt = states[l + 1]
-            y, m, r, ss = be.mlp_fwd(xs[-1], ss, slopes[l], Ws[l], nseg, eps[l + 1], moms[l + 1], rm, rv, nbt,
-                                     shifts[l + 1], gam[l + 1], bet[l + 1])
+            y, ci = be.mlp_fwd(xs[-1], cis[-1], slopes[l], Ws[l], nseg, eps[l + 1], moms[l + 1], rm, rv, nbt,
+                               shifts[l + 1], gam[l + 1], bet[l + 1])
             xs.append(y)
-            means.append(m)
-            rstds.append(r)
-        out, arg = be.rowbn_apply_max(xs[-1], K, means[-1], rstds[-1], gam[-1], bet[-1], slopes[L], torch.bfloat16, nseg)
-        ctx.save_for_backward(*xs, *means, *rstds, *[g for g in gam], *[b for b in bet], *Ws, out,
-                              *([arg] if arg is not None else []))
+            cis.append(ci)
+        mean_L, rstd_L = cis[-1][:, 2].contiguous(), cis[-1][:, 3].contiguous()
+        out, arg = be.rowbn_apply_max(xs[-1], K, mean_L, rstd_L, gam[-1], bet[-1], slopes[L], torch.bfloat16, nseg)
+        ctx.save_for_backward(*xs, *cis, *gam, *bet, *Ws, mean_L, rstd_L, out, *([arg] if arg is not None else []))
         ctx.cfg = (nseg, K, slopes, L)
         return out
 
@@ -1070,38 +1065,36 @@ class _MlpTail(torch.autograd.Function):
         nseg, K, slopes, L = ctx.cfg
         t = list(ctx.saved_tensors)
         n = L + 1
-        xs, means, rstds, gam, bet = t[:n], t[n:2 * n], t[2 * n:3 * n], t[3 * n:4 * n], t[4 * n:5 * n]
-        Ws = t[5 * n:5 * n + L]
-        out = t[5 * n + L]
-        arg = t[5 * n + L + 1] if K else None
+        xs, cis, gam, bet = t[:n], t[n:2 * n], t[2 * n:3 * n], t[3 * n:4 * n]
+        Ws = t[4 * n:4 * n + L]
+        mean_L, rstd_L, out = t[4 * n + L:4 * n + L + 3]
+        arg = t[4 * n + L + 3] if K else None
         be = backend_for(xs[0])
         gout = gout.contiguous()
         if gout.dtype != torch.bfloat16:
             gout = gout.to(torch.bfloat16)
         # which gradients are wanted: (x0, cfg, gamma_0, beta_0, [W, gamma, beta]*L)
         need = ctx.needs_input_grad
-        need_aff = [need[2] or need[3]] + [need[3 * l + 6 - 1] or need[3 * l + 6] for l in range(L)]
+        need_aff = [need[2] or need[3]] + [need[3 * l + 5] or need[3 * l + 6] for l in range(L)]
         need_w = [need[3 * l + 4] for l in range(L)]
         grads_aff = [None] * n
         grads_w = [None] * L
         # the last BatchNorm (+ act, + max): its sums come from (gout, out) alone
-        c12, dg, db = be.rowbn_bwd_sums(gout, xs[L], arg, out if K else None, K, means[L], rstds[L], gam[L], bet[L],
+        c12, dg, db = be.rowbn_bwd_sums(gout, xs[L], arg, out if K else None, K, mean_L, rstd_L, gam[L], bet[L],
                                         slopes[L], need_aff[L], nseg)
         grads_aff[L] = (dg, db)
-        g_next, arg_next, K_next = None, arg, K
+        _, cb = be.mlp_consts(mean_L, rstd_L, gam[L], bet[L], c12, False, True)
+        # the arriving gradient lives on each group's arg-max row: a * lrelu'(y) * gout per (group, channel)
+        g_next, arg_next, K_next = be.mlp_max_prep(gout, out, cb, slopes[L], nseg), arg, K
         for l in range(L, 0, -1):                    # layer l: x_{l-1} -> x_l
-            _, cb = be.mlp_consts(means[l], rstds[l], gam[l], bet[l], c12, False, True)
-            ci, _ = be.mlp_consts(means[l - 1], rstds[l - 1], gam[l - 1], bet[l - 1], None, True, False)
-            if l == L:
-                # the arriving gradient lives on each group's arg-max row: a * lrelu'(y) * gout per (group, channel)
-                g_next = be.mlp_max_prep(gout, out, cb, slopes[L], nseg)
             if need_w[l - 1]:
-                grads_w[l - 1] = be.mlp_wgrad(xs[l], g_next, arg_next, K_next, cb, xs[l - 1], ci, slopes[l - 1], nseg)
-            g_in, c12, dg, db = be.mlp_dgrad(xs[l], g_next, arg_next, K_next, cb, xs[l - 1], ci, slopes[l - 1],
-                                             Ws[l - 1], nseg, need_aff[l - 1])
+                grads_w[l - 1] = be.mlp_wgrad(xs[l], g_next, arg_next, K_next, cb, xs[l - 1], cis[l - 1], slopes[l - 1],
+                                              nseg)
+            g_in, c12, cb, dg, db = be.mlp_dgrad(xs[l], g_next, arg_next, K_next, cb, xs[l - 1], cis[l - 1],
+                                                 slopes[l - 1], Ws[l - 1], nseg, need_aff[l - 1])
             grads_aff[l - 1] = (dg, db)
             g_next, arg_next, K_next = g_in, None, 0
-        dx0 = be.mlp_bn_bwd_apply(g_next, xs[0], ci, c12, nseg) if need[0] else None
+        dx0 = be.mlp_bn_bwd_apply(g_next, xs[0], cis[0], c12, nseg) if need[0] else None
         res = [dx0, None, grads_aff[0][0], grads_aff[0][1]]
         for l in range(L):
             gw = grads_w[l]
@@ -1111,6 +1104,75 @@ class _MlpTail(torch.autograd.Function):
                 gw = gw.sum(0, keepdim=True)
             res += [gw, grads_aff[l + 1][0], grads_aff[l + 1][1]]
         return tuple(res)
+
+
+_IDENT = {}
+
+
+def _ident_consts(C_, device):
+    """(cb, ci) of an identity BatchNorm with zero backward sums: dx = gg, a = 1, xhat terms 0."""
+    key = (C_, device)
+    if key not in _IDENT:
+        cb = torch.zeros((1, 4, C_), dtype=torch.float32, device=device)
+        cb[0, 0] = 1.0                              # a | f*mu | e | f
+        ci = torch.zeros((1, 4, C_), dtype=torch.float32, device=device)
+        ci[0, 0] = 1.0                              # sc | sh | mu | rs
+        ci[0, 3] = 1.0
+        _IDENT[key] = (cb, ci)
+    return _IDENT[key]
+
+
+class _MlpTailPlain(torch.autograd.Function):
+    """x_0 -> [act_0] -> W_1 -> act_1 -> ... -> W_L -> act_L -> max over K on bf16 rows, NO BatchNorm: the MLP of
+    the generator's EdgeConv (gcn_lib/pointnet/gcn.py:207-211, norm == 'none') on the same fused MFMA kernels
+    with identity statistics -- no statistics passes, no finalize launches, dx never stored."""
+
+    @staticmethod
+    def forward(ctx, x0, K, slopes, *Ws):
+        be = backend_for(x0)
+        L = len(Ws)
+        xs = [x0]
+        for l in range(L):
+            y, _ = be.mlp_fwd(xs[-1], None, slopes[l], Ws[l], 1, stats=False)
+            xs.append(y)
+        out, arg = be.rowbn_fwd(xs[-1], K, 0.0, 0.0, False, None, None, None, None, slopes[L], None, None, torch.bfloat16)
+        ctx.save_for_backward(*xs, *Ws, out, arg)
+        ctx.cfg = (K, slopes, L)
+        return out
+
+    @staticmethod
+    def backward(ctx, gout):
+        K, slopes, L = ctx.cfg
+        t = list(ctx.saved_tensors)
+        xs, Ws, out, arg = t[:L + 1], t[L + 1:2 * L + 1], t[2 * L + 1], t[2 * L + 2]
+        be = backend_for(xs[0])
+        gout = gout.contiguous()
+        if gout.dtype != torch.bfloat16:
+            gout = gout.to(torch.bfloat16)
+        need = ctx.needs_input_grad                  # (x0, K, slopes, W_1..W_L)
+        grads_w = [None] * L
+        cb = _ident_consts(out.shape[1], out.device)[0]
+        g_next, arg_next, K_next = be.mlp_max_prep(gout, out, cb, slopes[L], 1), arg, K
+        for l in range(L, 0, -1):
+            cb = _ident_consts(xs[l].shape[1], out.device)[0]
+            ci = _ident_consts(xs[l - 1].shape[1], out.device)[1]
+            if need[3 + l - 1]:
+                grads_w[l - 1] = be.mlp_wgrad(xs[l], g_next, arg_next, K_next, cb, xs[l - 1], ci, slopes[l - 1], 1)[0]
+            if l > 1 or need[0]:
+                g_next = be.mlp_dgrad(xs[l], g_next, arg_next, K_next, cb, xs[l - 1], ci, slopes[l - 1], Ws[l - 1], 1,
+                                      False, sums=False)[0]
+            arg_next, K_next = None, 0
+        return (g_next if need[0] else None, None, None) + tuple(grads_w)
+
+
+def mlp_tail_plain(x0, weights, slopes, K):
+    """max_K act_L(W_L ... act_1(W_1 act_0(x0))) on bf16 rows x0 (P, C_0), no BatchNorm: (P/K, C_L) bf16.
+    weights: L tensors (C_l, C_{l-1}) fp32; slopes: L+1 LeakyReLU slopes in [0, 1] (1.0 = no activation)."""
+    L = len(weights)
+    _need(len(slopes) == L + 1 and L >= 1, "mlp_tail_plain: L weights, L+1 slopes")
+    _need(all(0.0 <= float(sl) <= 1.0 for sl in slopes), "mlp_tail_plain: LeakyReLU slopes in [0, 1]")
+    _need(all(w.dtype == torch.float32 and w.dim() == 2 for w in weights), "mlp_tail_plain: 2-D fp32 weights")
+    return _MlpTailPlain.apply(x0.contiguous(), int(K), tuple(float(s) for s in slopes), *[w.contiguous() for w in weights])
 
 
 def mlp_tail_supported(x, channels, K):

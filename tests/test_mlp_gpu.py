@@ -49,7 +49,8 @@ def test_mlp_fwd_matches_torch(hip, Cin, Cout, P, nseg):
     rm, rv = torch.zeros(Cout, device="cuda"), torch.ones(Cout, device="cuda")
     nbt = torch.zeros((), dtype=torch.int64, device="cuda")
     gamma, beta = torch.rand(Cout, device="cuda") + 0.5, torch.randn(Cout, device="cuda") * 0.1
-    y, mean, rstd, ss_out = hip.mlp_fwd(x, ss, 0.01, W, nseg, 1e-5, 0.1, rm, rv, nbt, None, gamma, beta)
+    y, ci = hip.mlp_fwd(x, ss, 0.01, W, nseg, 1e-5, 0.1, rm, rv, nbt, None, gamma, beta)
+    mean, rstd = ci[:, 2], ci[:, 3]
     ref = _ref_fwd(x, W, ss, 0.01, nseg)
     err = (y.float() - ref).abs()
     # same bf16 operands, fp32 accumulation in another order, ONE rounding of y to bf16: within one
@@ -63,7 +64,7 @@ def test_mlp_fwd_matches_torch(hip, Cin, Cout, P, nseg):
     assert torch.allclose(mean.double(), m_ref, rtol=0, atol=1e-5 * float(m_ref.abs().max() + v_ref.sqrt().max()))
     assert torch.allclose(rstd.double(), (v_ref + 1e-5).rsqrt(), rtol=1e-5, atol=0)
     a = gamma * rstd
-    assert torch.allclose(ss_out[:, 0], a) and torch.allclose(ss_out[:, 1], beta - mean * a, atol=1e-6)
+    assert torch.allclose(ci[:, 0], a) and torch.allclose(ci[:, 1], beta - mean * a, atol=1e-6)
     # running statistics chained segment after segment, unbiased variance, counter += nseg
     erm, erv = torch.zeros(Cout, dtype=torch.float64), torch.ones(Cout, dtype=torch.float64)
     for s in range(nseg):
@@ -81,7 +82,8 @@ def test_mlp_fwd_statistics_survive_a_large_mean(hip):
     W = torch.zeros(1, Cout, Cin).cuda()
     W[0, :, 1] = 8.0                                                  # constant part: 8
     W[0, :, 0] = 1.0                                                  # varying part: sigma 0.01
-    y, mean, rstd, _ = hip.mlp_fwd(x, None, 1.0, W, 1, 1e-5, 0.0, None, None, None, None, None, None)
+    y, ci = hip.mlp_fwd(x, None, 1.0, W, 1, 1e-5, 0.0, None, None, None, None, None, None)
+    mean, rstd = ci[:, 2], ci[:, 3]
     yd = y.double()
     assert torch.allclose(mean.double()[0], yd.mean(0), atol=1e-6)
     assert torch.allclose(rstd.double()[0], (yd.var(0, unbiased=False) + 1e-5).rsqrt(), rtol=1e-4)
@@ -93,6 +95,9 @@ def test_mlp_fwd_is_bitwise_reproducible(hip):
     b = hip.mlp_fwd(x, ss, 0.2, W, 3, 1e-5, 0.1, None, None, None, None, None, None)
     for u, v in zip(a, b):
         assert torch.equal(u, v)
+    # without statistics (a tail without BatchNorm): the same rows, no finalize
+    y2, none = hip.mlp_fwd(x, ss, 0.2, W, 3, stats=False)
+    assert none is None and torch.equal(y2, a[0])
 
 
 # ------------------------------------------------------------------ the whole tail, forward + backward
@@ -188,3 +193,57 @@ def test_mlp_tail_is_bitwise_reproducible():
         res.append((out,) + tuple(g) + (bns[1].running_var.clone(),))
     for a, b in zip(*res):
         assert torch.equal(a, b)
+
+
+# ------------------------------------------------------------------ EdgeConv MLP: the tail without BatchNorm
+@pytest.mark.parametrize("chain,K,P", [((64, 64, 128), 20, 512 * 20 * 6), ((128, 128, 256), 12, 512 * 12 * 4),
+                                         ((128, 128, 256), 4, 1000 * 4), ((64, 128), 9, 9 * 333)])
+def test_mlp_tail_plain_forward_backward(chain, K, P):
+    """ops.mlp_tail_plain (identity statistics) against the PyTorch statement of the EdgeConv MLP
+    (gcn_lib/pointnet/gcn.py:207-211): [conv -> LeakyReLU(0.2)]* -> max over the k neighbours."""
+    import tpgan_amd.ops as ops
+    torch.manual_seed(sum(chain) + K)
+    L = len(chain) - 1
+    x0 = torch.randn(P, chain[0]).bfloat16().cuda()
+    Ws = [(torch.randn(chain[l + 1], chain[l]) / chain[l] ** 0.5).cuda().requires_grad_(True) for l in range(L)]
+    slopes = [1.0] + [0.2] * L
+    xk = x0.clone().requires_grad_(True)
+    out = ops.mlp_tail_plain(xk, Ws, slopes, K)
+    gout = torch.randn(out.shape, device="cuda").bfloat16()
+    got = torch.autograd.grad(out, [xk] + Ws, gout)
+    xr = x0.float().clone().requires_grad_(True)
+    a = xr
+    for l in range(L):
+        a = _ste_bf16(_ste_bf16(a) @ _ste_bf16(Ws[l]).t())
+        a = torch.where(a > 0, a, a * 0.2)
+    ref = a.view(P // K, K, -1).max(1)[0]
+    want = torch.autograd.grad(ref, [xr] + Ws, gout.float())
+    err = float((out.float() - ref).abs().max() / ref.abs().max())
+    assert err <= 2e-2, err
+    for name, g, w in zip(["dx0"] + [f"dW{l + 1}" for l in range(L)], got, want):
+        assert g.shape == w.shape, (name, g.shape, w.shape)
+        rel = _rel(g.float(), w)
+        assert rel <= 3e-2, (name, rel)
+
+
+def test_edgeconv_fused_tail_equals_the_separate_launches():
+    """EdgeConv.forward_rows with the fused MFMA tail against the hipBLASLt + activation launches it
+    replaces, bf16 autocast, same module: outputs and all gradients."""
+    from tpgan_amd import graph_conv
+    from tpgan_amd.graph_conv import EdgeConv
+    torch.manual_seed(4)
+    m = EdgeConv(64, 256, k=12, aggregate="max", mlp_layer=True, bn=False, insn=False).cuda()
+    x = torch.randn(6, 512, 64, device="cuda")
+    res = []
+    for fused in (True, False):
+        graph_conv.FUSED_EDGE_TAILS[0] = fused
+        try:
+            xi = x.clone().requires_grad_(True)
+            with torch.autocast("cuda", dtype=torch.bfloat16):
+                y = m.forward_rows(xi)
+            g = torch.autograd.grad(y.float().square().sum(), [xi] + list(m.parameters()))
+            res.append((y.float(),) + tuple(t.float() for t in g))
+        finally:
+            graph_conv.FUSED_EDGE_TAILS[0] = True
+    for a, b in zip(*res):
+        assert a.shape == b.shape and _rel(a, b) <= 3e-2, _rel(a, b)

@@ -14,7 +14,7 @@ import numpy as np
 import torch
 
 import tpgan_amd  # noqa: F401
-from tpgan_amd import configs, set_abstraction
+from tpgan_amd import configs, graph_conv, set_abstraction
 
 name = sys.argv[1] if len(sys.argv) > 1 else "cfg2"
 torch.backends.cudnn.enabled = False
@@ -23,10 +23,10 @@ np.random.seed(0)
 clips = [configs.make_clip(name, seed=s, device=dev) for s in range(4)]
 steppers = {}
 for fused in (True, False):
-    set_abstraction.FUSED_TAILS[0] = fused
+    set_abstraction.FUSED_TAILS[0] = graph_conv.FUSED_EDGE_TAILS[0] = fused
     models = configs.build_models(name, dev, capturable=True)
     steppers[fused] = configs.graphed_step(name, models, clips[0], amp_dtype=torch.bfloat16)
-set_abstraction.FUSED_TAILS[0] = True
+set_abstraction.FUSED_TAILS[0] = graph_conv.FUSED_EDGE_TAILS[0] = True
 res = {}
 for rnd in range(3):
     for fused in (True, False):

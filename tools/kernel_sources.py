@@ -7,7 +7,6 @@ sorted by launches per step -- the input for deciding what to fuse next.
     python tools/kernel_sources.py [max_us]      # only kernels shorter than max_us (default 8)
 """
 import collections
-import importlib.util
 import os
 import sys
 
@@ -17,25 +16,24 @@ import numpy as np
 import torch
 from torch.profiler import ProfilerActivity, profile
 
-spec = importlib.util.spec_from_file_location("bench", os.path.join(ROOT, "bench.py"))
-b = importlib.util.module_from_spec(spec)
-argv, sys.argv = sys.argv, ["bench.py"]
-spec.loader.exec_module(b)
+import tpgan_amd  # noqa: F401,E402
+from tpgan_amd import configs  # noqa: E402
+
+argv = sys.argv
 max_us = float(argv[1]) if len(argv) > 1 else 8.0
+update_D = not (len(argv) > 2 and argv[2] == "gonly")      # "gonly": the generator-only body (the step's critical chain)
 
 torch.backends.cudnn.enabled = False
 dev = torch.device("cuda", 0)
 np.random.seed(0)
-models = b.build(dev, capturable=True)
-clips = [b.fluid_clip(8, 4096, 8, 3, seed=s, device=dev) for s in range(2)]
-from tpgan_amd.gan_step_graph import GraphedFluidStep
-G, Ds, Dt, opts = models
-step = GraphedFluidStep(G, Ds, Dt, opts, b.OPT, clips[0][0], clips[0][1], 1.0, torch.bfloat16, None)
+models = configs.build_models("cfg2", dev, capturable=True)
+clips = [configs.make_clip("cfg2", seed=s, device=dev) for s in range(2)]
+step = configs.graphed_step("cfg2", models, clips[0], amp_dtype=torch.bfloat16)
 step._load(*clips[1])
-step._run_eager(True)                                       # the body the graph captured, run eagerly
+step._run_eager(update_D)                                   # the body the graph captured, run eagerly
 torch.cuda.synchronize()
 with profile(activities=[ProfilerActivity.CPU, ProfilerActivity.CUDA], with_stack=True) as prof:
-    step._run_eager(True)
+    step._run_eager(update_D)
     torch.cuda.synchronize()
 
 
