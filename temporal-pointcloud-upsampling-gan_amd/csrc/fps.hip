@@ -62,9 +62,13 @@ __global__ __launch_bounds__(BLOCK) void fps_kernel(const float *__restrict__ xy
     for (int t = 0; t < PPT; ++t) {
         const int k = tid * PPT + t;
         const bool in = k < N;
-        px[t] = in ? x[(size_t)k * 3 + 0] : 0.0f;
-        py[t] = in ? x[(size_t)k * 3 + 1] : 0.0f;
-        pz[t] = in ? x[(size_t)k * 3 + 2] : 0.0f;
+        // clamped, UNCONDITIONAL loads (a load under `in ?` becomes a branch per element: 16 of them made
+        // hipcc spill 744 bytes per lane in the variant without the LDS copy -- 6 us per round at 16384 points)
+        const float *pk = x + (size_t)(in ? k : N - 1) * 3;
+        const float vx = pk[0], vy = pk[1], vz = pk[2];
+        px[t] = in ? vx : 0.0f;
+        py[t] = in ? vy : 0.0f;
+        pz[t] = in ? vz : 0.0f;
         float mag = px[t] * px[t];
         mag = mag + py[t] * py[t];
         mag = mag + pz[t] * pz[t];
@@ -73,8 +77,10 @@ __global__ __launch_bounds__(BLOCK) void fps_kernel(const float *__restrict__ xy
     }
     int old = start ? tpg_clamp_idx(start[blockIdx.x], N) : 0;       // pointnet2: always point 0
     if (tid == 0) out[0] = old;
-    // the first pick's coordinates (clouds without an LDS copy: from memory, once)
+    // the first pick's coordinates (clouds without an LDS copy: from memory, once) and point 0's (the
+    // pick when no point is eligible), so that NO global load is left inside the round loop
     float ox = x[(size_t)old * 3], oy = x[(size_t)old * 3 + 1], oz = x[(size_t)old * 3 + 2];
+    const float zx = x[0], zy = x[1], zz = x[2];
     if (NW > 1 || USE_LDS) __syncthreads();
 
     for (int j = 1; j < m; ++j) {
@@ -82,6 +88,7 @@ __global__ __launch_bounds__(BLOCK) void fps_kernel(const float *__restrict__ xy
 
         int best = __float_as_int(-1.0f);
         int besti = 0;
+        float bx = 0.0f, by = 0.0f, bz = 0.0f;    // (no LDS copy: the lane's best point travels with its index)
 #pragma unroll
         for (int t = 0; t < PPT; ++t) {
             const float d = tpg_sq3(px[t], py[t], pz[t], ox, oy, oz);
@@ -92,6 +99,7 @@ __global__ __launch_bounds__(BLOCK) void fps_kernel(const float *__restrict__ xy
             const bool up = b2 > best;            // strict: first (smallest) index wins inside a lane
             best = up ? b2 : best;
             besti = up ? tid * PPT + t : besti;
+            if constexpr (!USE_LDS) { bx = up ? px[t] : bx; by = up ? py[t] : by; bz = up ? pz[t] : bz; }
         }
         // the value's max, then the index of the FIRST lane that attains it (lower lane <=> lower
         // indices): the mask is never empty, the maximum is somebody's value
@@ -102,15 +110,8 @@ __global__ __launch_bounds__(BLOCK) void fps_kernel(const float *__restrict__ xy
             // no LDS copy of the cloud (N > 12288): the winning lane hands on its point's coordinates
             // itself -- a round trip to L2 for 12 bytes cost 3 of the 3.5 us of a round at 16384 points
             if (lane == src) {
-                const int bt = bi - tid * PPT;
-                float sx = px[0], sy = py[0], sz = pz[0];
-#pragma unroll
-                for (int t = 1; t < PPT; ++t) {
-                    const bool hit = bt == t;
-                    sx = hit ? px[t] : sx; sy = hit ? py[t] : sy; sz = hit ? pz[t] : sz;
-                }
                 float *w = wxyz + ((j & 1) * 16 + wave) * 4;
-                w[0] = sx; w[1] = sy; w[2] = sz;
+                w[0] = bx; w[1] = by; w[2] = bz;
             }
         }
         int win = wave;
@@ -125,12 +126,9 @@ __global__ __launch_bounds__(BLOCK) void fps_kernel(const float *__restrict__ xy
         }
         old = mx >= 0 ? bi : 0;                   // mx < 0 <=> no eligible point at all
         if constexpr (!USE_LDS) {
-            if (mx >= 0) {
-                const float *w = wxyz + ((j & 1) * 16 + win) * 4;     // (single wave: its own LDS writes, in order)
-                ox = w[0]; oy = w[1]; oz = w[2];
-            } else {
-                ox = x[0]; oy = x[1]; oz = x[2];
-            }
+            const float *w = wxyz + ((j & 1) * 16 + win) * 4;         // (single wave: its own LDS writes, in order)
+            const float4 wv = *reinterpret_cast<const float4 *>(w);
+            ox = mx >= 0 ? wv.x : zx; oy = mx >= 0 ? wv.y : zy; oz = mx >= 0 ? wv.z : zz;
         }
         if (tid == 0) out[j] = old;
     }
