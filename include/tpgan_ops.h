@@ -55,6 +55,17 @@ int tpg_knn_f32(const float *p1, const float *p2, const int64_t *len1,
                 const int64_t *len2, int B, int P1, int P2, int D, int K,
                 float r2, float *dist, int64_t *idx, void *stream);
 
+/* Plain kNN (no radius) in D = 32 / 64 feature space, 2 <= K <= 24, 16-byte aligned rows: the path
+ * tpg_knn_f32 takes by itself for clouds of >= 2048 points (gcn_lib/pointnet/gcn.py:38,258 at cfg5's
+ * 4096-point low-resolution clouds; upsampling_network.py:159-174 rollouts).  A Gram-matrix filter on
+ * the f32 matrix cores (v_mfma_f32_32x32x2_f32) rules candidates out with a rigorous rounding bound, the
+ * survivors are re-ranked with the canonical distance, and queries the bound cannot settle are redone by
+ * the exhaustive kernel: the output equals tpg_knn_f32's bit for bit.  redo = 0 (diagnostic) skips that
+ * last launch and leaves idx[b][i][0] = -2 on the unsettled queries. */
+int tpg_knn_mfma_f32(const float *p1, const float *p2, const int64_t *len1,
+                     const int64_t *len2, int B, int P1, int P2, int D, int K,
+                     float *dist, int64_t *idx, int redo, void *stream);
+
 /* The same radius search (r > 0, D = 3, K <= 64) on a UNIFORM GRID, for clouds where the exhaustive
  * kernel stops being free (loss.py:256-265 at 16384 points per cloud; the 10^4..10^5-point rollout,
  * upsampling_network.py:159-174): cells of edge max(r, extent/64), points counting-sorted by cell,

@@ -21,6 +21,8 @@
 //     minimum, one DPP wave reduction at the end.
 // The kernel is HBM/L2-light (each cloud is a few KB..1.5 MB and stays in L2);
 // its bound is VALU issue + cross-lane latency, see DESIGN.md.
+#include <cstdlib>
+
 #include "knn_select.hpp"
 #include "tpg_common.hpp"
 
@@ -65,7 +67,9 @@ __device__ __forceinline__ float knn_dist(const float *__restrict__ qs,
     return acc;
 }
 
-template <int D_T, bool RADIUS>
+constexpr long long KM_REDO_MARK = -2;   // knn_mfma.hpp: first index slot of a query the filter could not settle
+
+template <int D_T, bool RADIUS, bool REDO = false>
 __global__ __launch_bounds__(KNN_WAVES * 64) void knn_kernel(
     const float *__restrict__ p1, const float *__restrict__ p2,
     const int64_t *__restrict__ len1, const int64_t *__restrict__ len2, int B, int P1, int P2,
@@ -92,6 +96,7 @@ __global__ __launch_bounds__(KNN_WAVES * 64) void knn_kernel(
     }
     __syncthreads();
     if (!valid) return;
+    if (REDO && idx[q * K] != KM_REDO_MARK) return;       // only the queries the matrix-core filter left open
 
     const float pad_d = RADIUS ? -1.0f : 0.0f;
     const long long pad_i = RADIUS ? -1 : 0;
@@ -223,6 +228,39 @@ __global__ __launch_bounds__(KNN_WAVES * 64) void knn_tile_kernel(
     }
 }
 
+#include "knn_mfma.hpp"
+
+#ifndef TPG_KNN_MFMA_MIN_POINTS
+#define TPG_KNN_MFMA_MIN_POINTS 2048    // clouds from which the matrix-core filter beats the tiled exhaustive kernel
+#endif
+
+// the filter kernel, then (redo) the exhaustive kernel on the queries it marked
+template <int D_T>
+int knn_mfma_launch(const float *p1, const float *p2, const int64_t *len1, const int64_t *len2, int B, int P1, int P2,
+                    int K, float *dist, int64_t *idx, bool redo, hipStream_t st) {
+    static bool attr_set = false;
+    if (!attr_set) {
+        if (hipFuncSetAttribute(reinterpret_cast<const void *>(&knn_mfma_kernel<D_T>), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                (int)km_smem_bytes<D_T>()) != hipSuccess)
+            return TPG_ERR_LAUNCH;
+        attr_set = true;
+    }
+    const int gx = (P1 + KM_Q - 1) / KM_Q;
+    const long long total = (long long)gx * B;
+    if (total > (1ll << 30)) return TPG_ERR_ARG;
+    const unsigned grid = (unsigned)((total + 7) / 8 * 8);
+    hipLaunchKernelGGL((knn_mfma_kernel<D_T>), dim3(grid), dim3(KM_WAVES * 64), km_smem_bytes<D_T>(), st, p1, p2, len1, len2,
+                       P1, P2, K, gx, (int)total, dist, idx);
+    TPG_RETURN_IF_LAUNCH_FAILED();
+    if (redo) {
+        const dim3 rg((unsigned)((P1 + KNN_WAVES - 1) / KNN_WAVES), (unsigned)B);
+        hipLaunchKernelGGL((knn_kernel<D_T, false, true>), rg, dim3(KNN_WAVES * 64), sizeof(float) * KNN_WAVES * D_T, st, p1, p2,
+                           len1, len2, B, P1, P2, D_T, K, -1.0f, dist, idx);
+        TPG_RETURN_IF_LAUNCH_FAILED();
+    }
+    return TPG_OK;
+}
+
 template <bool RADIUS>
 int knn_launch(const float *p1, const float *p2, const int64_t *len1, const int64_t *len2, int B,
                int P1, int P2, int D, int K, float r2, float *dist, int64_t *idx,
@@ -234,6 +272,14 @@ int knn_launch(const float *p1, const float *p2, const int64_t *len1, const int6
     if (smem > 64 * 1024) return TPG_ERR_UNSUPPORTED;
     // the vector path also needs 16-B aligned rows: D % 4 == 0 and aligned bases
     const bool al = ((reinterpret_cast<uintptr_t>(p1) | reinterpret_cast<uintptr_t>(p2)) & 15) == 0;
+#ifndef TPG_KNN_NO_MFMA
+    // large feature-space clouds: Gram filter on the f32 matrix cores + exact re-ranking (knn_mfma.hpp)
+    static const bool mfma_on = [] { const char *e = getenv("TPG_KNN_MFMA"); return !(e && e[0] == '0'); }();   // A/B switch
+    if (mfma_on && !RADIUS && al && K > 1 && K <= KM_MAX_K && (D == 32 || D == 64) && P2 >= TPG_KNN_MFMA_MIN_POINTS) {
+        if (D == 32) return knn_mfma_launch<32>(p1, p2, len1, len2, B, P1, P2, K, dist, idx, true, st);
+        return knn_mfma_launch<64>(p1, p2, len1, len2, B, P1, P2, K, dist, idx, true, st);
+    }
+#endif
     // feature-space searches with several neighbours: the query-tiled kernel
 #ifndef TPG_KNN_NO_TILE
     // feature-space searches: the query-tiled kernel.  Measured on (24,512,D) clouds
@@ -308,6 +354,17 @@ extern "C" int tpg_knn_f32(const float *p1, const float *p2, const int64_t *len1
     if (r2 >= 0.0f)
         return knn_launch<true>(p1, p2, len1, len2, B, P1, P2, D, K, r2, dist, idx, tpg_stream(stream));
     return knn_launch<false>(p1, p2, len1, len2, B, P1, P2, D, K, r2, dist, idx, tpg_stream(stream));
+}
+
+extern "C" int tpg_knn_mfma_f32(const float *p1, const float *p2, const int64_t *len1, const int64_t *len2, int B, int P1,
+                                int P2, int D, int K, float *dist, int64_t *idx, int redo, void *stream) {
+    if (B < 0 || P1 < 0 || P2 < 0 || K <= 1) return TPG_ERR_ARG;
+    if ((D != 32 && D != 64) || K > KM_MAX_K) return TPG_ERR_UNSUPPORTED;
+    if ((long long)B * P1 == 0) return TPG_OK;
+    if (!p1 || !p2 || !dist || !idx || B > 65535) return TPG_ERR_ARG;
+    if ((reinterpret_cast<uintptr_t>(p1) | reinterpret_cast<uintptr_t>(p2)) & 15) return TPG_ERR_ARG;
+    if (D == 32) return knn_mfma_launch<32>(p1, p2, len1, len2, B, P1, P2, K, dist, idx, redo != 0, tpg_stream(stream));
+    return knn_mfma_launch<64>(p1, p2, len1, len2, B, P1, P2, K, dist, idx, redo != 0, tpg_stream(stream));
 }
 
 extern "C" int tpg_chamfer_fwd_f32(const float *src, const float *tgt, int B, int N, int M,

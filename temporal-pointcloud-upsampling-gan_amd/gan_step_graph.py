@@ -36,6 +36,7 @@ Multi-GPU: with `sync.world_size > 1` the step is captured as two graphs (`_phas
 them (RCCL calls are kept out of capture).
 """
 import contextlib
+import gc
 import os
 
 import numpy as np
@@ -459,16 +460,25 @@ class GraphedFluidStep:
                 # with a process group alive, its watchdog thread polls events while we capture: only
                 # THIS thread's unsafe calls may invalidate the capture then
                 mode = {"capture_error_mode": "thread_local"} if self.sync.world_size > 1 else {}
-                with torch.cuda.graph(g, pool=pool, **mode):
-                    try:
-                        fn()
-                    except BaseException:
-                        # leave the capture joinable: an unjoined side stream turns the original
-                        # error into "capturing stream has unjoined work" and poisons the stream
-                        self._join_sides()
-                        torch.cuda.current_stream(self.dev).wait_stream(self.branch)
-                        torch.cuda.current_stream(self.dev).wait_stream(self.branch2)
-                        raise
+                # no cyclic garbage collection inside the capture: a collection there may finalise an OLDER
+                # stepper's CUDAGraph objects (they sit in reference cycles), and destroying a graph / freeing
+                # its pool while this thread captures aborts the process or corrupts later replays
+                gc_was_on = gc.isenabled()
+                gc.disable()
+                try:
+                    with torch.cuda.graph(g, pool=pool, **mode):
+                        try:
+                            fn()
+                        except BaseException:
+                            # leave the capture joinable: an unjoined side stream turns the original
+                            # error into "capturing stream has unjoined work" and poisons the stream
+                            self._join_sides()
+                            torch.cuda.current_stream(self.dev).wait_stream(self.branch)
+                            torch.cuda.current_stream(self.dev).wait_stream(self.branch2)
+                            raise
+                finally:
+                    if gc_was_on:
+                        gc.enable()
                 pool = g.pool()
                 graphs.append((g, None if reduce_module is None else reduce_module["flat"]))
             self._graphs[update_D] = graphs

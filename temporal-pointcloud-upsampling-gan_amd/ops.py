@@ -165,6 +165,20 @@ class HipBackend:
                    -1.0 if r2 is None else r2, _ptr(dist), _ptr(idx))
         return dist, idx
 
+    def knn_mfma(self, p1, p2, len1, len2, K, redo=True):
+        """The matrix-core filter path of tpg_knn_f32 called directly (D = 32 / 64, 2 <= K <= 24): what
+        tpg_knn_f32 runs by itself on clouds of >= 2048 points.  redo=False leaves idx[..., 0] = -2 on the
+        queries the filter could not settle (tests and tuning count them)."""
+        B, P1, D = p1.shape
+        P2 = p2.shape[1]
+        dist = torch.zeros((B, P1, K), dtype=torch.float32, device=p1.device)
+        idx = torch.zeros((B, P1, K), dtype=torch.int64, device=p1.device)
+        self._call("tpg_knn_mfma_f32", "knn_mfma", 4 * B * D * (P1 + P2) + 12 * B * P1 * K, p1,
+                   _ptr(p1), _ptr(p2), _ptr(len1), _ptr(len2), B, P1, P2, D, K, _ptr(dist), _ptr(idx), 1 if redo else 0,
+                   flops=2.0 * 2 * B * P1 * P2 * D)
+
+        return dist, idx
+
     def cubic_interp(self, query, pos, field, cutoff):
         B, Nq, _ = query.shape
         Np, F_ = pos.shape[1], field.shape[2]

@@ -49,6 +49,56 @@ def test_knn_bit_exact(hip, B, P1, P2, D, K):
     assert np.array_equal(d.cpu().numpy(), rd)
 
 
+def _feature_cloud(rng, B, P, D, kind):
+    """Feature-space clouds as the generator's bottleneck layers produce them: a few-dimensional manifold
+    embedded in D dims plus noise ("manifold"), iid normal ("normal"), the same far from the origin
+    ("offset": the Gram form cancels badly unless centred), and a cloud of 1/4 exact duplicates ("dups")."""
+    if kind == "manifold":
+        z = rng.standard_normal((B, P, 3)).astype(np.float32)
+        x = np.tanh(z @ rng.standard_normal((3, D)).astype(np.float32)) + 0.05 * rng.standard_normal((B, P, D)).astype(np.float32)
+    else:
+        x = rng.standard_normal((B, P, D)).astype(np.float32)
+    if kind == "offset":
+        x += 300.0
+    if kind == "dups":
+        x[:, P // 4 * 3:] = x[:, :P - P // 4 * 3]
+    return np.ascontiguousarray(x.astype(np.float32))
+
+
+@pytest.mark.parametrize("B,P1,P2,D,K,kind", [
+    (2, 4096, 4096, 32, 20, "manifold"), (1, 4096, 4096, 64, 12, "manifold"), (1, 2048, 2048, 32, 10, "normal"),
+    (1, 3000, 5000, 64, 8, "normal"), (1, 4096, 4096, 32, 20, "offset"), (1, 2500, 2500, 32, 20, "dups"),
+    (1, 700, 16384, 64, 24, "manifold")])
+def test_knn_matrix_core_filter_bit_exact(hip, B, P1, P2, D, K, kind):
+    """tpg_knn_f32 on clouds of >= 2048 points in 32 / 64 dims runs the Gram filter on the f32 matrix cores and
+    re-ranks the survivors exactly (csrc/knn_mfma.hpp): indices and distances equal the oracle's bit for bit,
+    whatever share of the queries fell back to the exhaustive kernel -- and on benign clouds that share is small
+    (a wrong operand layout would send every query there and still pass the first assertion)."""
+    rng = np.random.default_rng(P1 + P2 + D + K)
+    p2 = _feature_cloud(rng, B, P2, D, kind)
+    p1 = p2 if P1 == P2 else _feature_cloud(rng, B, P1, D, kind)
+    d, i = hip.knn(dev(p1), dev(p2), None, None, K, None)
+    rd, ri = R.knn(p1, p2, K)
+    assert np.array_equal(i.cpu().numpy(), ri)
+    assert np.array_equal(d.cpu().numpy(), rd)
+    _, raw = hip.knn_mfma(dev(p1), dev(p2), None, None, K, redo=False)
+    raw = raw.cpu().numpy()
+    open_ = raw[:, :, 0] == -2
+    print(f"matrix-core kNN {kind} D={D} K={K} P2={P2}: {open_.mean() * 100:.2f} % of the queries left to the exhaustive kernel")
+    assert np.array_equal(raw[~open_], ri[~open_])           # what the filter settled IS the answer
+    if kind in ("manifold", "normal"):
+        assert open_.mean() < 0.02
+
+
+def test_knn_matrix_core_filter_ragged(hip):
+    rng = np.random.default_rng(77)
+    p1, p2 = _feature_cloud(rng, 3, 2300, 32, "normal"), _feature_cloud(rng, 3, 4100, 32, "normal")
+    l1, l2 = np.array([2300, 1000, 0]), np.array([4100, 2049, 40])
+    d, i = hip.knn(dev(p1), dev(p2), dev(l1), dev(l2), 16, None)
+    rd, ri = R.knn(p1, p2, 16, l1, l2)
+    assert np.array_equal(i.cpu().numpy(), ri) and np.array_equal(d.cpu().numpy(), rd)
+
+
 def test_knn_all_identical_points(hip):
     p = np.full((1, 200, 3), 999.0, np.float32)   # a cloud of hard-masking dummies
     d, i = hip.knn(dev(p), dev(p), None, None, 16, None)
