@@ -318,6 +318,20 @@ int tpg_cubic_interp_f32(const float *query, const float *pos, const float *fiel
                          int F, float cutoff, float *out_plain, float *out_pad, int32_t *hits,
                          void *stream);
 
+/* The EdgeConv MLP tail at the generator's small channel counts (gcn_lib/pointnet/gcn.py:207-211 inside
+ * IDGCNLayer, gcn.py:229-231): out[n] = max_j lrelu_s2(W2 . lrelu_s1(W1 . h[n*K + j])), h (P*K, H) rows of edge
+ * features, W1 (C1, H), W2 (C2, C1) fp32, no bias; (H, C1, C2) = (16, 16, 32) only (TPG_ERR_UNSUPPORTED
+ * otherwise), 1 <= K <= 255, 0 <= slopes <= 1.  h / out / gout / gh are bf16 (is_bf16 = 1) or fp32; arithmetic
+ * is fp32 on the vector ALUs (weights as scalar operands).  Forward: out (P, C2) and the arg-max byte of each
+ * (point, channel) (first maximum).  Backward (recomputes the hidden layer from h): gh (P*K, H), dW1, dW2
+ * (fp32, per-wave slabs in `ws` summed in a fixed order). */
+size_t tpg_small_tail_workspace_bytes(long long P, int K);
+int tpg_small_tail_fwd(const void *h, int is_bf16, const float *W1, const float *W2, float slope1, float slope2,
+                       long long P, int K, int H, int C1, int C2, void *out, unsigned char *arg, void *stream);
+int tpg_small_tail_bwd(const void *h, const void *out, const void *gout, const unsigned char *arg, int is_bf16,
+                       const float *W1, const float *W2, float slope1, float slope2, long long P, int K, int H,
+                       int C1, int C2, void *gh, float *dW1, float *dW2, void *ws, void *stream);
+
 #ifdef __cplusplus
 }
 #endif

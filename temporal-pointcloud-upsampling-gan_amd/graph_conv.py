@@ -425,7 +425,19 @@ class EdgeConv(nn.Module):
         """[conv, LeakyReLU]* -> max over the k neighbours of h (B,N,k,H) on the fused MFMA kernels
         (ops.mlp_tail_plain, csrc/mlp_fused.hip) where they take the shapes: bf16 rows on the GPU, supported
         channel pairs, bare convs.  -> (B,N,C_out) or None."""
-        if not (FUSED_EDGE_TAILS[0] and self.aggregate == "max" and h.is_cuda and h.dtype == torch.bfloat16):
+        if not (FUSED_EDGE_TAILS[0] and self.aggregate == "max" and h.is_cuda):
+            return None
+        if (len(mods) == 4 and all(isinstance(m, nn.Conv2d) and m.bias is None for m in mods[0::2])
+                and all(isinstance(m, nn.LeakyReLU) and 0.0 <= m.negative_slope <= 1.0 for m in mods[1::2])
+                and ops.small_tail_supported(h, (h.shape[-1], mods[0].out_channels, mods[2].out_channels), h.shape[2])
+                and mods[0].in_channels == h.shape[-1] and mods[2].in_channels == mods[0].out_channels):
+            # the IDGCN blocks' 16 -> 16 -> 32 tails: one launch each way on the vector ALUs (csrc/mlp_small.hip)
+            B, N, k, H = h.shape
+            out = ops.small_tail(h.reshape(B * N * k, H), mods[0].weight.view(mods[0].out_channels, -1),
+                                 mods[2].weight.view(mods[2].out_channels, -1), mods[1].negative_slope,
+                                 mods[3].negative_slope, k)
+            return out.view(B, N, mods[2].out_channels)
+        if h.dtype != torch.bfloat16:
             return None
         convs, slopes = [], [1.0]
         for i in range(0, len(mods), 2):

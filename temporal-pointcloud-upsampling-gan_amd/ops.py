@@ -501,6 +501,38 @@ class HipBackend:
                    float(slope_in), P, Cin, Cout, nseg, mode, _ptr(dW), _ptr(ws), flops=2 * P * Cin * Cout)
         return dW
 
+    def small_tail_fwd(self, h, W1, W2, s1, s2, K):
+        """h (P*K, 16) bf16 / f32 -> out (P, 32) of h's dtype, arg (P, 32) u8 (csrc/mlp_small.hip)."""
+        E, H = h.shape
+        P = E // K
+        C1, C2 = W1.shape[0], W2.shape[0]
+        out = torch.empty((P, C2), dtype=h.dtype, device=h.device)
+        arg = torch.empty((P, C2), dtype=torch.uint8, device=h.device)
+        self._call("tpg_small_tail_fwd", "small_tail_fwd", h.element_size() * (E * H + P * C2) + P * C2, h,
+                   _ptr(h), 1 if h.dtype == torch.bfloat16 else 0, _ptr(W1), _ptr(W2), float(s1), float(s2), P, int(K),
+                   H, C1, C2, _ptr(out), _ptr(arg), flops=2 * E * (H * C1 + C1 * C2))
+        return out, arg
+
+    def small_tail_bwd(self, h, out, gout, arg, W1, W2, s1, s2, K):
+        """-> gh (P*K, 16) of h's dtype, dW1 (16,16) f32, dW2 (32,16) f32."""
+        E, H = h.shape
+        P = E // K
+        C1, C2 = W1.shape[0], W2.shape[0]
+        gh = torch.empty_like(h)
+        dW1 = torch.empty((C1, H), dtype=torch.float32, device=h.device)
+        dW2 = torch.empty((C2, C1), dtype=torch.float32, device=h.device)
+        need = max(16, self.lib.tpg_small_tail_workspace_bytes(P, int(K)) // 4)
+        key = ("small_tail", h.device, torch.cuda.current_stream(h.device).cuda_stream)
+        ws = self._ws.get(key)
+        if ws is None or ws.numel() < need:
+            ws = torch.empty(need, dtype=torch.float32, device=h.device)
+            self._ws[key] = ws
+        self._call("tpg_small_tail_bwd", "small_tail_bwd", h.element_size() * (2 * E * H + 2 * P * C2) + P * C2, h,
+                   _ptr(h), _ptr(out), _ptr(gout), _ptr(arg), 1 if h.dtype == torch.bfloat16 else 0, _ptr(W1), _ptr(W2),
+                   float(s1), float(s2), P, int(K), H, C1, C2, _ptr(gh), _ptr(dW1), _ptr(dW2), _ptr(ws),
+                   flops=2 * E * (2 * H * C1 + 2 * C1 * C2 + H * C1))
+        return gh, dW1, dW2
+
     def mlp_bn_bwd_apply(self, g, x, ci, c12, nseg):
         P, Cc = x.shape
         dx = torch.empty_like(x)
@@ -1187,6 +1219,45 @@ def mlp_tail_plain(x0, weights, slopes, K):
     _need(all(0.0 <= float(sl) <= 1.0 for sl in slopes), "mlp_tail_plain: LeakyReLU slopes in [0, 1]")
     _need(all(w.dtype == torch.float32 and w.dim() == 2 for w in weights), "mlp_tail_plain: 2-D fp32 weights")
     return _MlpTailPlain.apply(x0.contiguous(), int(K), tuple(float(s) for s in slopes), *[w.contiguous() for w in weights])
+
+
+SMALL_TAIL_CHANNELS = (16, 16, 32)
+
+
+class _SmallTail(torch.autograd.Function):
+    """max_K lrelu(W2 lrelu(W1 h)) at the (16, 16, 32) channels of the IDGCN EdgeConvs, one launch each way
+    (csrc/mlp_small.hip); only h, the output and the arg-max bytes are kept for the backward."""
+
+    @staticmethod
+    def forward(ctx, h, W1, W2, s1, s2, K):
+        be = backend_for(h)
+        w1, w2 = W1.detach().float().contiguous(), W2.detach().float().contiguous()
+        out, arg = be.small_tail_fwd(h, w1, w2, s1, s2, K)
+        ctx.save_for_backward(h, out, arg, w1, w2)
+        ctx.cfg = (s1, s2, K, W1.dtype, W2.dtype)
+        return out
+
+    @staticmethod
+    def backward(ctx, gout):
+        h, out, arg, w1, w2 = ctx.saved_tensors
+        s1, s2, K, t1, t2 = ctx.cfg
+        be = backend_for(h)
+        gh, dW1, dW2 = be.small_tail_bwd(h, out, gout.to(h.dtype).contiguous(), arg, w1, w2, s1, s2, K)
+        return (gh if ctx.needs_input_grad[0] else None, dW1.to(t1) if ctx.needs_input_grad[1] else None,
+                dW2.to(t2) if ctx.needs_input_grad[2] else None, None, None, None)
+
+
+def small_tail_supported(h, channels, K):
+    return (h.is_cuda and h.dtype in (torch.bfloat16, torch.float32) and tuple(channels) == SMALL_TAIL_CHANNELS
+            and 0 < K <= 255)
+
+
+def small_tail(h, W1, W2, slope1, slope2, K):
+    """h (P*K, 16) rows (bf16 or fp32) of K consecutive edges per point -> (P, 32):
+    max over the K edges of lrelu(W2 lrelu(W1 h)); W1 (16,16), W2 (32,16), no bias, slopes in [0, 1]."""
+    _need(0.0 <= float(slope1) <= 1.0 and 0.0 <= float(slope2) <= 1.0, "small_tail: LeakyReLU slopes in [0, 1]")
+    _need(h.dim() == 2 and h.shape[0] % int(K) == 0, "small_tail: (P*K, 16) rows")
+    return _SmallTail.apply(h.contiguous(), W1, W2, float(slope1), float(slope2), int(K))
 
 
 def mlp_tail_supported(x, channels, K):

@@ -8,6 +8,7 @@ stored values and must match an fp64 recomputation from them to 1e-5."""
 import numpy as np
 import pytest
 import torch
+import torch.nn.functional as F
 
 pytestmark = pytest.mark.gpu
 
@@ -247,3 +248,81 @@ def test_edgeconv_fused_tail_equals_the_separate_launches():
             graph_conv.FUSED_EDGE_TAILS[0] = True
     for a, b in zip(*res):
         assert a.shape == b.shape and _rel(a, b) <= 3e-2, _rel(a, b)
+
+
+# ------------------------------------------------------------ the 16 -> 16 -> 32 tail of the IDGCN EdgeConvs
+def _small_tail_reference(h, W1, W2, s1, s2, K):
+    z2 = F.leaky_relu(h.float() @ W1.t(), s1) @ W2.t()
+    P = h.shape[0] // K
+    return F.leaky_relu(z2.view(P, K, -1).max(1)[0], s2)
+
+
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+@pytest.mark.parametrize("P,K", [(12288, 20), (12288, 10), (1000, 9), (37, 3), (5, 1)])
+def test_small_tail_forward_backward(dtype, P, K):
+    """csrc/mlp_small.hip against plain PyTorch fp32 on the same rows: output, gradient to the rows, both
+    weight gradients.  The kernels compute in fp32 whatever the row type: fp32 rows to 1e-5 (north_star's
+    tolerance), bf16 rows to the rounding of the stored output / gradient (2^-8)."""
+    from tpgan_amd import ops
+    torch.manual_seed(P + K)
+    h = torch.randn(P * K, 16, device="cuda").to(dtype)
+    W1 = (torch.randn(16, 16, device="cuda") * 0.3).requires_grad_(True)
+    W2 = (torch.randn(32, 16, device="cuda") * 0.3).requires_grad_(True)
+    g = torch.randn(P, 32, device="cuda").to(dtype)
+    hi = h.clone().requires_grad_(True)
+    y = ops.small_tail(hi, W1, W2, 0.2, 0.2, K)
+    assert y.dtype == dtype and y.shape == (P, 32)
+    gh, g1, g2 = torch.autograd.grad(y, [hi, W1, W2], g)
+    hr = h.float().clone().requires_grad_(True)
+    yr = _small_tail_reference(hr, W1, W2, 0.2, 0.2, K)
+    rh, r1, r2 = torch.autograd.grad(yr, [hr, W1, W2], g.float())
+    tol = 1e-5 if dtype == torch.float32 else 2.0 ** -7
+    assert _rel(y.float(), yr) <= tol, _rel(y.float(), yr)
+    assert _rel(gh.float(), rh) <= tol, _rel(gh.float(), rh)
+    assert _rel(g1, r1) <= max(tol, 2e-5) and _rel(g2, r2) <= max(tol, 2e-5), (_rel(g1, r1), _rel(g2, r2))
+
+
+def test_small_tail_routes_ties_to_the_first_maximum_and_is_reproducible():
+    from tpgan_amd import ops
+    torch.manual_seed(3)
+    K, P = 12, 640
+    base = torch.randn(P, 1, 16, device="cuda")
+    h = base.expand(P, K, 16).reshape(P * K, 16).contiguous()            # K identical edges per point: every channel ties
+    W1 = torch.randn(16, 16, device="cuda", requires_grad=True)
+    W2 = torch.randn(32, 16, device="cuda", requires_grad=True)
+    hi = h.clone().requires_grad_(True)
+    y = ops.small_tail(hi, W1, W2, 0.2, 0.2, K)
+    gh, g1, g2 = torch.autograd.grad(y.sum(), [hi, W1, W2])
+    gh = gh.view(P, K, 16)
+    assert float(gh[:, 1:].abs().max()) == 0.0 and float(gh[:, 0].abs().max()) > 0.0    # all of it on edge 0
+    hi2 = h.clone().requires_grad_(True)
+    gh2, g1b, g2b = torch.autograd.grad(ops.small_tail(hi2, W1, W2, 0.2, 0.2, K).sum(), [hi2, W1, W2])
+    assert torch.equal(gh.reshape(-1, 16), gh2) and torch.equal(g1, g1b) and torch.equal(g2, g2b)
+
+
+@pytest.mark.parametrize("amp", [False, True])
+def test_idgcn_small_tails_equal_the_separate_launches(amp):
+    """IDGCNLayer.forward_rows (two EdgeConvs with 16 -> 16 -> 32 tails) with the one-launch tails against the
+    GEMM + activation launches they replace.  fp32: the two forms sum in different orders, outputs agree to 1e-4;
+    a near-tie of the max over the neighbours may then pick another edge and move its share of a gradient
+    (measured 6e-4 of a weight gradient's norm): 2e-3.  bf16 autocast: the unfused path rounds every
+    intermediate to bf16, the fused one only its output (measured 3.1e-2 on one weight gradient): 5e-2."""
+    from tpgan_amd import graph_conv
+    from tpgan_amd.graph_conv import IDGCNLayer
+    torch.manual_seed(6)
+    m = IDGCNLayer(128, 128, bn=False, insn=False, residual=True).cuda()
+    x = torch.randn(4, 512, 128, device="cuda")
+    res = []
+    for fused in (True, False):
+        graph_conv.FUSED_EDGE_TAILS[0] = fused
+        try:
+            xi = x.clone().requires_grad_(True)
+            with torch.autocast("cuda", dtype=torch.bfloat16, enabled=amp):
+                y = m.forward_rows(xi)
+            g = torch.autograd.grad(y.float().square().sum(), [xi] + list(m.parameters()))
+            res.append((y.float(),) + tuple(t.float() for t in g))
+        finally:
+            graph_conv.FUSED_EDGE_TAILS[0] = True
+    assert _rel(res[0][0], res[1][0]) <= (3e-2 if amp else 1e-4)
+    for a, b in zip(*res):
+        assert a.shape == b.shape and _rel(a, b) <= (5e-2 if amp else 2e-3), _rel(a, b)
