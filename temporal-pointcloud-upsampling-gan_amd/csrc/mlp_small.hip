@@ -231,20 +231,31 @@ __global__ __launch_bounds__(SB_WAVES * 64) void small_tail_bwd_kernel(
     }
 }
 
-__global__ __launch_bounds__(256) void small_tail_reduce_kernel(const float *__restrict__ slabs, int nslab,
-                                                                float *__restrict__ dW1, float *__restrict__ dW2) {
-    const int i = blockIdx.x * 256 + threadIdx.x;
-    if (i >= SM_NW) return;
+// slabs -> dW1 | dW2: 64 outputs x 16 slab groups per workgroup; a group adds its slabs in slab order, the 16 group
+// sums are added in group order (the order is fixed by the launch shape alone: same bits every run)
+__global__ __launch_bounds__(1024) void small_tail_reduce_kernel(const float *__restrict__ slabs, int nslab,
+                                                                 float *__restrict__ dW1, float *__restrict__ dW2) {
+    __shared__ float part[16][64];
+    const int col = threadIdx.x & 63, g = threadIdx.x >> 6;
+    const int i = blockIdx.x * 64 + col;
     float s = 0.0f;
-    for (int w = 0; w < nslab; ++w) s += slabs[(size_t)w * SM_NW + i];
-    if (i < SM_C1 * SM_H) dW1[i] = s;
-    else dW2[i - SM_C1 * SM_H] = s;
+#pragma unroll 4
+    for (int w = g; w < nslab; w += 16) s += slabs[(size_t)w * SM_NW + i];
+    part[g][col] = s;
+    __syncthreads();
+    if (g == 0) {
+        float t = part[0][col];
+#pragma unroll
+        for (int k = 1; k < 16; ++k) t += part[k][col];
+        if (i < SM_C1 * SM_H) dW1[i] = t;
+        else dW2[i - SM_C1 * SM_H] = t;
+    }
 }
 
 int small_bwd_blocks(long long P) {
     const long long tiles = (P + 15) / 16;
     long long blocks = (tiles + SB_WAVES - 1) / SB_WAVES;
-    const long long cap = 256 * 2;                           // 2048 persistent waves: the slabs stay few (6 MB)
+    const long long cap = 256;                               // 1024 persistent waves (one per SIMD): 3 MB of slabs
     if (blocks > cap) blocks = cap;
     return (int)(blocks < 1 ? 1 : blocks);
 }
@@ -304,7 +315,7 @@ extern "C" int tpg_small_tail_bwd(const void *h, const void *out, const void *go
                            static_cast<const float *>(out), static_cast<const float *>(gout), arg, W1, W2, slope1, slope2, P, K,
                            static_cast<float *>(gh), slabs);
     TPG_RETURN_IF_LAUNCH_FAILED();
-    hipLaunchKernelGGL(small_tail_reduce_kernel, dim3((SM_NW + 255) / 256), dim3(256), 0, st, slabs, blocks * SB_WAVES, dW1, dW2);
+    hipLaunchKernelGGL(small_tail_reduce_kernel, dim3(SM_NW / 64), dim3(1024), 0, st, slabs, blocks * SB_WAVES, dW1, dW2);
     TPG_RETURN_IF_LAUNCH_FAILED();
     return TPG_OK;
 }
