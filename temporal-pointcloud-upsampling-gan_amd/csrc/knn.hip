@@ -22,6 +22,9 @@
 // The kernel is HBM/L2-light (each cloud is a few KB..1.5 MB and stays in L2);
 // its bound is VALU issue + cross-lane latency, see DESIGN.md.
 #include <cstdlib>
+#include <type_traits>
+
+#include <hip/hip_bf16.h>
 
 #include "knn_select.hpp"
 #include "tpg_common.hpp"
@@ -235,12 +238,12 @@ __global__ __launch_bounds__(KNN_WAVES * 64) void knn_tile_kernel(
 #endif
 
 // the filter kernel, then (redo) the exhaustive kernel on the queries it marked
-template <int D_T>
-int knn_mfma_launch(const float *p1, const float *p2, const int64_t *len1, const int64_t *len2, int B, int P1, int P2,
-                    int K, float *dist, int64_t *idx, bool redo, hipStream_t st) {
+template <int D_T, int M>
+int knn_mfma_launch_m(const float *p1, const float *p2, const int64_t *len1, const int64_t *len2, int B, int P1, int P2,
+                      int K, float *dist, int64_t *idx, bool redo, hipStream_t st) {
     static bool attr_set = false;
     if (!attr_set) {
-        if (hipFuncSetAttribute(reinterpret_cast<const void *>(&knn_mfma_kernel<D_T>), hipFuncAttributeMaxDynamicSharedMemorySize,
+        if (hipFuncSetAttribute(reinterpret_cast<const void *>(&knn_mfma_kernel<D_T, M>), hipFuncAttributeMaxDynamicSharedMemorySize,
                                 (int)km_smem_bytes<D_T>()) != hipSuccess)
             return TPG_ERR_LAUNCH;
         attr_set = true;
@@ -249,7 +252,7 @@ int knn_mfma_launch(const float *p1, const float *p2, const int64_t *len1, const
     const long long total = (long long)gx * B;
     if (total > (1ll << 30)) return TPG_ERR_ARG;
     const unsigned grid = (unsigned)((total + 7) / 8 * 8);
-    hipLaunchKernelGGL((knn_mfma_kernel<D_T>), dim3(grid), dim3(KM_WAVES * 64), km_smem_bytes<D_T>(), st, p1, p2, len1, len2,
+    hipLaunchKernelGGL((knn_mfma_kernel<D_T, M>), dim3(grid), dim3(KM_WAVES * 64), km_smem_bytes<D_T>(), st, p1, p2, len1, len2,
                        P1, P2, K, gx, (int)total, dist, idx);
     TPG_RETURN_IF_LAUNCH_FAILED();
     if (redo) {
@@ -259,6 +262,18 @@ int knn_mfma_launch(const float *p1, const float *p2, const int64_t *len1, const
         TPG_RETURN_IF_LAUNCH_FAILED();
     }
     return TPG_OK;
+}
+
+// minima kept per lane: 2 M points are guaranteed below the threshold, ~2.4 M expected; K + 8 <= 2 M keeps the
+// verification margin, a small M keeps the candidate list (64 slots) from overflowing and the insert chain short
+template <int D_T>
+int knn_mfma_launch(const float *p1, const float *p2, const int64_t *len1, const int64_t *len2, int B, int P1, int P2,
+                    int K, float *dist, int64_t *idx, bool redo, hipStream_t st) {
+    // (from 16384 points the gap between the K-th and the 2M-th neighbour is what has to beat the rounding bound
+    // on low-dimensional clouds: the longest list, whatever K)
+    if (K <= 12 && P2 < 16384) return knn_mfma_launch_m<D_T, 10>(p1, p2, len1, len2, B, P1, P2, K, dist, idx, redo, st);
+    if (K <= 20 && P2 < 16384) return knn_mfma_launch_m<D_T, 14>(p1, p2, len1, len2, B, P1, P2, K, dist, idx, redo, st);
+    return knn_mfma_launch_m<D_T, 16>(p1, p2, len1, len2, B, P1, P2, K, dist, idx, redo, st);
 }
 
 template <bool RADIUS>

@@ -26,7 +26,6 @@
 //            exhaustive kernel, one wave per flagged query -- redoes it.  The output is the exhaustive
 //            kernels' output bit for bit in every case; only the time depends on the data.
 #pragma once
-#include <type_traits>
 
 typedef float km_f32x16 __attribute__((ext_vector_type(16)));
 
@@ -38,8 +37,9 @@ constexpr int KM_Q = KM_WAVES * 32;     // queries per workgroup
 template <int D_T>
 constexpr int km_tile_rows() { return D_T == 32 ? 128 : 64; }   // points per staged tile: two workgroups' LDS must fit a CU
 constexpr int KM_CAP = 64;              // candidate slots per query
-constexpr int KM_M = 16;                // sub-tile minima kept per lane
-constexpr int KM_MAX_K = 24;            // K' = 2 KM_M = 32 guaranteed candidates must exceed K with room to spare
+constexpr float KM_BIG = 1.0e30f;       // the norm of a padding row / an empty list entry: finite (no 0 x INF in the matrix unit), never a hit
+constexpr int KM_MIN_VALID = 1024;      // fewer valid points than this in a cloud: no filter (32 entries per lane are the floor)
+constexpr int KM_MAX_K = 24;            // 2 M guaranteed candidates (M = 10 / 14 / 16 minima kept per lane) must exceed K with room to spare
 constexpr long long KM_REDO = KM_REDO_MARK;   // first index slot of a query the exhaustive kernel must redo
 
 template <int CTRL>
@@ -50,26 +50,46 @@ __device__ __forceinline__ float km_dpp_f32(float v) {
 template <int D_T>
 constexpr size_t km_smem_bytes() {
     constexpr int KM_TP = km_tile_rows<D_T>();
-    return sizeof(float) * (2 * KM_TP * (D_T + 4) + 2 * KM_TP + D_T + KM_WAVES * D_T) + sizeof(int) * (KM_Q + KM_Q * KM_CAP + 2) +
+    return sizeof(float) * (2 * KM_TP * (D_T + 4) + D_T + KM_WAVES * D_T) + sizeof(int) * (KM_Q + KM_Q * KM_CAP + 2) +
            sizeof(tpg_u64) * KM_WAVES * 64;
 }
 
-template <int D_T>
+typedef __bf16 km_bf16x8 __attribute__((ext_vector_type(8)));
+
+// v_min / v_max as they are, for values the compiler's own instructions produced: fminf / fmaxf put a canonicalising
+// v_max x, x, x in front of their operands (quiet-NaN semantics), a third of the sorted-insert chain.  NOT for the
+// accumulators of a matrix instruction: the hazard recogniser does not look inside inline asm, and a v_min issued
+// before the matrix unit has written its result reads the old register (measured: thresholds far too high, 12 % of the
+// queries overflowed their candidate list).  No NaN reaches these (finite rows, 1e30 on padding).
+__device__ __forceinline__ float km_min(float a, float b) { float r; asm("v_min_f32 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b)); return r; }
+__device__ __forceinline__ float km_max(float a, float b) { float r; asm("v_max_f32 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b)); return r; }
+
+// x = hi + lo + r with hi = bf16(x), lo = bf16(x - hi) (x - hi is exact in fp32): |r| <= 2^-16 |x|
+__device__ __forceinline__ void km_split2(float a, float b, unsigned &hi, unsigned &lo) {
+    const __hip_bfloat16 ha = __float2bfloat16(a), hb = __float2bfloat16(b);
+    const unsigned short ua = *reinterpret_cast<const unsigned short *>(&ha), ub = *reinterpret_cast<const unsigned short *>(&hb);
+    hi = (unsigned)ua | ((unsigned)ub << 16);
+    const float ra = a - __uint_as_float((unsigned)ua << 16), rb = b - __uint_as_float((unsigned)ub << 16);
+    const __hip_bfloat16 la = __float2bfloat16(ra), lb = __float2bfloat16(rb);
+    lo = (unsigned)*reinterpret_cast<const unsigned short *>(&la) | ((unsigned)*reinterpret_cast<const unsigned short *>(&lb) << 16);
+}
+
+template <int D_T, int KM_M>
 __global__ __launch_bounds__(KM_WAVES * 64, 8 / KM_WAVES) void knn_mfma_kernel(
     const float *__restrict__ p1, const float *__restrict__ p2, const int64_t *__restrict__ len1,
     const int64_t *__restrict__ len2, int P1, int P2, int K, int gx, int total, float *__restrict__ dist,
     int64_t *__restrict__ idx) {
     constexpr int KM_TP = km_tile_rows<D_T>();
-    constexpr int LD = D_T + 4;                    // row stride of the LDS tile: b128 reads of 16 rows hit 64 banks
+    constexpr int LD = D_T + 4;                    // LDS row in 32-bit words: D/2 of hi pairs, D/2 of lo pairs, 4 with |y|^2 (16 rows of b128 reads: 64 banks)
     constexpr int V = D_T / 4;                     // float4 per row
     constexpr int RPP = KM_WAVES * 64 / V;         // rows staged per pass of the workgroup
     constexpr int NP = KM_TP / RPP;                // passes per tile
-    constexpr int G = D_T / 8;                     // b128 operand reads per row and half
-    static_assert(NP >= 1 && KM_TP % RPP == 0 && (V == 8 || V == 16), "tile staging shape");
+    constexpr int KS = D_T / 16;                   // k-steps of the 32x32x16 matrix instruction
+    constexpr int NS = KM_TP / 32;                 // 32-row sub-tiles per staged tile
+    static_assert(NP >= 1 && KM_TP % RPP == 0 && (V == 8 || V == 16) && NS % 2 == 0, "tile staging shape");
     extern __shared__ __attribute__((aligned(16))) unsigned char km_smem[];
-    float *tile = reinterpret_cast<float *>(km_smem);                 // [2][KM_TP][LD]   -2 (x - origin)
-    float *nrm = tile + 2 * KM_TP * LD;                               // [2][KM_TP]       |x - origin|^2, INF on padding rows
-    float *org = nrm + 2 * KM_TP;                                     // [D_T]
+    unsigned *tile = reinterpret_cast<unsigned *>(km_smem);           // [2][KM_TP][LD]   bf16 pairs of -2 (x - origin): hi | lo | norm triplet
+    float *org = reinterpret_cast<float *>(tile + 2 * KM_TP * LD);    // [D_T]
     float *qrow = org + D_T;                                          // [KM_WAVES][D_T]  tail: the query as given
     tpg_u64 *keys = reinterpret_cast<tpg_u64 *>(qrow + KM_WAVES * D_T);   // [KM_WAVES][64]
     int *cnt = reinterpret_cast<int *>(keys + KM_WAVES * 64);         // [KM_Q]
@@ -89,7 +109,7 @@ __global__ __launch_bounds__(KM_WAVES * 64, 8 / KM_WAVES) void knn_mfma_kernel(
     const int n2 = len2 ? min((int)len2[b], P2) : P2;
     float *od = dist + (size_t)b * P1 * K;
     int64_t *oi = idx + (size_t)b * P1 * K;
-    if (n2 < KM_CAP) {                             // nothing to filter: the exhaustive kernel handles (and pads) these
+    if (n2 < KM_MIN_VALID) {                       // too few points for the thresholds: the exhaustive kernel handles (and pads) these
         for (int t = tid; t < KM_Q; t += KM_WAVES * 64)
             if (q0 + t < P1) oi[(size_t)(q0 + t) * K] = KM_REDO;
         return;
@@ -100,20 +120,28 @@ __global__ __launch_bounds__(KM_WAVES * 64, 8 / KM_WAVES) void knn_mfma_kernel(
     if (tid == 0) *pmax = 0u;
     __syncthreads();
 
-    // ---- this lane's query: dims 8g + 4h + i of query q0 + 32 wave + c, centred -------------------------
+    // ---- this lane's query (B operand): dims 16 ks + 8 h .. + 8 of query q0 + 32 wave + c, centred, split ----
     const int qi = q0 + wave * 32 + c;
-    float bq[D_T / 2];
+    uint4 bqh[KS], bql[KS];
     float nq = 0.0f;
 #pragma unroll
-    for (int g = 0; g < G; ++g) {
-        float4 x = make_float4(0.f, 0.f, 0.f, 0.f);
-        const float4 o = *reinterpret_cast<const float4 *>(org + 8 * g + 4 * h);
-        if (qi < P1) {
-            x = *reinterpret_cast<const float4 *>(p1 + ((size_t)b * P1 + qi) * D_T + 8 * g + 4 * h);
-            x.x -= o.x; x.y -= o.y; x.z -= o.z; x.w -= o.w;
+    for (int ks = 0; ks < KS; ++ks) {
+        float y[8];
+#pragma unroll
+        for (int v = 0; v < 2; ++v) {
+            float4 x = make_float4(0.f, 0.f, 0.f, 0.f);
+            const float4 o = *reinterpret_cast<const float4 *>(org + 16 * ks + 8 * h + 4 * v);
+            if (qi < P1) {
+                x = *reinterpret_cast<const float4 *>(p1 + ((size_t)b * P1 + qi) * D_T + 16 * ks + 8 * h + 4 * v);
+                x.x -= o.x; x.y -= o.y; x.z -= o.z; x.w -= o.w;
+            }
+            y[4 * v] = x.x; y[4 * v + 1] = x.y; y[4 * v + 2] = x.z; y[4 * v + 3] = x.w;
+            nq += x.x * x.x + x.y * x.y + x.z * x.z + x.w * x.w;
         }
-        bq[4 * g + 0] = x.x; bq[4 * g + 1] = x.y; bq[4 * g + 2] = x.z; bq[4 * g + 3] = x.w;
-        nq += x.x * x.x + x.y * x.y + x.z * x.z + x.w * x.w;
+        km_split2(y[0], y[1], bqh[ks].x, bql[ks].x);
+        km_split2(y[2], y[3], bqh[ks].y, bql[ks].y);
+        km_split2(y[4], y[5], bqh[ks].z, bql[ks].z);
+        km_split2(y[6], y[7], bqh[ks].w, bql[ks].w);
     }
     nq += __shfl_xor(nq, 32);
 
@@ -143,24 +171,44 @@ __global__ __launch_bounds__(KM_WAVES * 64, 8 / KM_WAVES) void knn_mfma_kernel(
             s += km_dpp_f32<0x141>(s);
             if constexpr (V == 16) s += km_dpp_f32<0x140>(s);
             const int row = buf * KM_TP + sr + p * RPP;
-            *reinterpret_cast<float4 *>(tile + row * LD + 4 * sv) = make_float4(-2.0f * y.x, -2.0f * y.y, -2.0f * y.z, -2.0f * y.w);
-            if (sv == 0) nrm[row] = pv[p] ? s : INFINITY;
+            uint2 hi, lo;
+            km_split2(-2.0f * y.x, -2.0f * y.y, hi.x, lo.x);
+            km_split2(-2.0f * y.z, -2.0f * y.w, hi.y, lo.y);
+            *reinterpret_cast<uint2 *>(tile + row * LD + 2 * sv) = hi;
+            *reinterpret_cast<uint2 *>(tile + row * LD + D_T / 2 + 2 * sv) = lo;
+            if (sv == 0) {
+                // |y_p|^2 as three bf16 terms (8 + 8 + 8 significant bits: exact) in the row's four spare words:
+                // one more matrix instruction against (1, 1, 1, 0 ...) starts the accumulator at the norm, instead
+                // of four LDS reads and sixteen moves per lane and sub-tile
+                const float nv = pv[p] ? s : KM_BIG;
+                const __hip_bfloat16 n0 = __float2bfloat16(nv);
+                const float r0 = nv - __bfloat162float(n0);
+                const __hip_bfloat16 n1 = __float2bfloat16(r0);
+                const __hip_bfloat16 n2b = __float2bfloat16(r0 - __bfloat162float(n1));
+                const unsigned w0 = (unsigned)*reinterpret_cast<const unsigned short *>(&n0) |
+                                    ((unsigned)*reinterpret_cast<const unsigned short *>(&n1) << 16);
+                const unsigned w1 = (unsigned)*reinterpret_cast<const unsigned short *>(&n2b);
+                *reinterpret_cast<uint4 *>(tile + row * LD + D_T) = make_uint4(w0, w1, 0u, 0u);
+            }
             if (pv[p]) mymax = fmaxf(mymax, s);
         }
     };
 
+    // B operand of the norm step: ones at k = 0, 1, 2 (lanes of the lower half), zeros elsewhere
+    const uint4 ones = h == 0 ? make_uint4(0x3f803f80u, 0x00003f80u, 0u, 0u) : make_uint4(0u, 0u, 0u, 0u);
+    const km_f32x16 zero16 = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
     float lst[KM_M];
 #pragma unroll
-    for (int i = 0; i < KM_M; ++i) lst[i] = INFINITY;
+    for (int i = 0; i < KM_M; ++i) lst[i] = KM_BIG;
     const int ql = wave * 32 + c;                  // this lane's query within the workgroup
     const int NT = (n2 + KM_TP - 1) / KM_TP;
+    // rows per entry of a lane's list of minima: 16 (one sub-tile) on small clouds, 32 on large ones -- a lane must see
+    // well over KM_M entries for its KM_M-th smallest to be a tight threshold
+    const bool pairs = n2 >= 4096;
 
-    // One sweep over the cloud.  Within a step the 32-row sub-tiles are software-pipelined: the VALU work on
-    // sub-tile s-1's accumulators (minima / hit mask) is interleaved, three instructions per gap, between the 16
-    // dependent matrix instructions of sub-tile s (each waits 64 cycles for its predecessor): a wave always has
-    // a matrix instruction to offer, so the two waves of a SIMD keep the matrix pipe busy instead of running
-    // their VALU phases side by side.
-    constexpr int NS = KM_TP / 32;
+    // One sweep over the cloud.  d' = |y_p|^2 - 2 y_p.y_q (the query's own norm is added in the tail): the accumulator
+    // starts from the row norms and takes 3 KS matrix instructions (hi.hi + hi.lo + lo.hi) per 32 x 32 pairs.
+    // The VALU work on sub-tile s-1 (minima / hit mask) sits between the matrix instructions of sub-tile s.
     auto sweep = [&](auto second_tag, int step0, float tauf) {
         constexpr bool SECOND = decltype(second_tag)::value;
         for (int t = 0; t < NT; ++t) {
@@ -169,26 +217,27 @@ __global__ __launch_bounds__(KM_WAVES * 64, 8 / KM_WAVES) void knn_mfma_kernel(
             if (more) prefetch(t + 1 == NT ? 0 : t + 1);
             km_f32x16 prev;
             unsigned hits = 0;
+            float held = KM_BIG;
 #pragma unroll
             for (int sub = 0; sub <= NS; ++sub) {
                 km_f32x16 acc;
                 if (sub < NS) {
-                    const float *arow = tile + (cur * KM_TP + sub * 32 + c) * LD + 4 * h;
-                    float4 a4[G];
+                    const unsigned *arow = tile + (cur * KM_TP + sub * 32 + c) * LD + 4 * h;
+                    uint4 ah[KS], al[KS];
 #pragma unroll
-                    for (int g = 0; g < G; ++g) a4[g] = *reinterpret_cast<const float4 *>(arow + 8 * g);
-#pragma unroll
-                    for (int grp = 0; grp < 4; ++grp) {
-                        const float4 n4 = *reinterpret_cast<const float4 *>(nrm + cur * KM_TP + sub * 32 + 8 * grp + 4 * h);
-                        acc[4 * grp + 0] = n4.x + nq; acc[4 * grp + 1] = n4.y + nq;
-                        acc[4 * grp + 2] = n4.z + nq; acc[4 * grp + 3] = n4.w + nq;
+                    for (int ks = 0; ks < KS; ++ks) {
+                        ah[ks] = *reinterpret_cast<const uint4 *>(arow + 8 * ks);
+                        al[ks] = *reinterpret_cast<const uint4 *>(arow + D_T / 2 + 8 * ks);
                     }
+                    const uint4 an = *reinterpret_cast<const uint4 *>(tile + (cur * KM_TP + sub * 32 + c) * LD + D_T);
+                    acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(km_bf16x8, an), __builtin_bit_cast(km_bf16x8, ones), zero16, 0, 0, 0);
 #pragma unroll
-                    for (int g = 0; g < G; ++g) {
-                        acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a4[g].x, bq[4 * g + 0], acc, 0, 0, 0);
-                        acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a4[g].y, bq[4 * g + 1], acc, 0, 0, 0);
-                        acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a4[g].z, bq[4 * g + 2], acc, 0, 0, 0);
-                        acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a4[g].w, bq[4 * g + 3], acc, 0, 0, 0);
+                    for (int ks = 0; ks < KS; ++ks) {
+                        const km_bf16x8 Ah = __builtin_bit_cast(km_bf16x8, ah[ks]), Al = __builtin_bit_cast(km_bf16x8, al[ks]);
+                        const km_bf16x8 Bh = __builtin_bit_cast(km_bf16x8, bqh[ks]), Bl = __builtin_bit_cast(km_bf16x8, bql[ks]);
+                        acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(Al, Bh, acc, 0, 0, 0);
+                        acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(Ah, Bl, acc, 0, 0, 0);
+                        acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(Ah, Bh, acc, 0, 0, 0);
                     }
                 }
                 if (sub > 0) {
@@ -196,23 +245,25 @@ __global__ __launch_bounds__(KM_WAVES * 64, 8 / KM_WAVES) void knn_mfma_kernel(
                         float v = fminf(fminf(prev[0], prev[1]), fminf(prev[2], prev[3]));
 #pragma unroll
                         for (int r = 4; r < 16; r += 4) v = fminf(v, fminf(fminf(prev[r], prev[r + 1]), fminf(prev[r + 2], prev[r + 3])));
+                        if (pairs && (sub & 1)) {
+                            held = v;                                   // first half of a 32-row entry
+                        } else {
+                            v = km_min(v, held);
+                            held = KM_BIG;
 #pragma unroll
-                        for (int i = 0; i < KM_M; ++i) {
-                            const float lo = fminf(v, lst[i]);
-                            v = fmaxf(v, lst[i]);
-                            lst[i] = lo;
+                            for (int i = 0; i < KM_M; ++i) {
+                                const float lo = km_min(v, lst[i]);
+                                v = km_max(v, lst[i]);
+                                lst[i] = lo;
+                            }
                         }
                     } else {
+                        // bit r of `hits` (reversed: slot 15 - r) = sign of prev[r] - nextafter(tau): one subtract and
+                        // one funnel shift per value instead of compare, select and or
                         hits = 0;
 #pragma unroll
-                        for (int r = 0; r < 16; ++r) hits |= prev[r] <= tauf ? 1u << r : 0u;
-                    }
-                }
-                if (sub < NS && sub > 0) {
-#pragma unroll
-                    for (int m = 0; m < D_T / 2; ++m) {
-                        __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);     // one matrix instruction
-                        __builtin_amdgcn_sched_group_barrier(0x002, 3, 0);     // three VALU instructions of the sub-tile before
+                        for (int r = 0; r < 16; ++r)
+                            hits = __builtin_amdgcn_alignbit(hits, __float_as_uint(prev[r] - tauf), 31);
                     }
                 }
                 if constexpr (SECOND) {
@@ -221,7 +272,7 @@ __global__ __launch_bounds__(KM_WAVES * 64, 8 / KM_WAVES) void knn_mfma_kernel(
                             int pos = atomicAdd(&cnt[ql], __popc(hits));
                             const int base = t * KM_TP + (sub - 1) * 32 + 4 * h;
                             while (hits) {
-                                const int r = __builtin_ctz(hits);
+                                const int r = 15 - __builtin_ctz(hits);
                                 hits &= hits - 1;
                                 if (pos < KM_CAP) cbuf[ql * KM_CAP + pos] = base + 8 * (r >> 2) + (r & 3);
                                 ++pos;
@@ -241,36 +292,72 @@ __global__ __launch_bounds__(KM_WAVES * 64, 8 / KM_WAVES) void knn_mfma_kernel(
     __syncthreads();
     sweep(std::false_type{}, 0, 0.0f);
     const float tau = fmaxf(lst[KM_M - 1], __shfl_xor(lst[KM_M - 1], 32));
-    sweep(std::true_type{}, NT, fminf(tau, 3.0e38f));     // finite: padding rows carry d~ = INF and never hit
+    // hits are d' <= tau, tested as d' - tau_up < 0 with tau_up the next float above tau (below the padding rows' 1e30)
+    const float tau_c = fminf(tau, 1.0e29f);
+    const float tau_up = __uint_as_float(__float_as_uint(tau_c) + (tau_c >= 0.0f ? 1u : 0xffffffffu));
+    sweep(std::true_type{}, NT, tau_c == 0.0f ? 1.0e-45f : tau_up);
     if (sv == 0) atomicMax(pmax, __float_as_uint(mymax));
     __syncthreads();
 
     // ---- tail: exact re-ranking, one wave per query ------------------------------------------------------
+    // |d~ - d_canonical| <= E_q = c1 |y_q| max|y_p| + c2 (|y_q| + max|y_p|)^2 :
+    //   c1 = 2^-13: the three dropped cross terms of the split products, 6.06 2^-16 |y_q||y_p|, with a third to spare;
+    //   c2 = (8 D + 64) 2^-24: fp32 accumulation of the 3 D / 16 matrix steps (taken as 4 ulp each of the running
+    //        magnitude), the two norms, the centring and the canonical sum itself, doubled.
     const float sq_pmax = sqrtf(__uint_as_float(*pmax));
-    constexpr float CD = (float)(4 * D_T + 32) * 5.9604644775390625e-8f;       // (4 D + 32) 2^-24
+    constexpr float C1 = 1.220703125e-4f;                                         // 2^-13
+    constexpr float C2 = (float)(8 * D_T + 64) * 5.9604644775390625e-8f;          // (8 D + 64) 2^-24
     float *qs = qrow + wave * D_T;
-    tpg_u64 *ks = keys + wave * 64;
+    tpg_u64 *ks_ = keys + wave * 64;
     const tpg_u64 INF = ~0ull;
-    for (int qq = 0; qq < 32; ++qq) {
+    // a query's candidate rows are a dependent chain (list entry -> row address -> 2 x D bytes from L2): the rows of
+    // query qq + 1 are fetched into a second register set before query qq is ranked
+    constexpr int V4 = D_T / 4;
+    auto fetch = [&](int qq, float4 (&row)[V4], int &j, int &n) {
         const int i = q0 + wave * 32 + qq;
-        if (i >= P1) break;
+        j = -1;
+        n = -1;
+        if (qq >= 32 || i >= P1 || i >= n1) return;
+        n = cnt[wave * 32 + qq];
+        if (n <= KM_CAP && lane < n) {
+            j = cbuf[(wave * 32 + qq) * KM_CAP + lane];
+            const float4 *c4 = reinterpret_cast<const float4 *>(cb + (size_t)j * D_T);
+#pragma unroll
+            for (int d = 0; d < V4; ++d) row[d] = c4[d];
+        }
+    };
+    auto finish = [&](int qq, const float4 (&row)[V4], int j, int n) {
+        const int i = q0 + wave * 32 + qq;
+        if (i >= P1) return;
         if (i >= n1) {
             if (lane < K) { od[(size_t)i * K + lane] = 0.0f; oi[(size_t)i * K + lane] = 0; }
-            continue;
+            return;
         }
-        const float tq = __uint_as_float((unsigned)__builtin_amdgcn_readlane((int)__float_as_uint(tau), qq));
-        const float sq = sqrtf(__uint_as_float((unsigned)__builtin_amdgcn_readlane((int)__float_as_uint(nq), qq))) + sq_pmax;
-        const float eq = CD * sq * sq;
-        const int n = cnt[wave * 32 + qq];
+        const float nqq = __uint_as_float((unsigned)__builtin_amdgcn_readlane((int)__float_as_uint(nq), qq));
+        const float tq = __uint_as_float((unsigned)__builtin_amdgcn_readlane((int)__float_as_uint(tau), qq)) + nqq;
+        const float sqq = sqrtf(nqq);
+        const float eq = C1 * sqq * sq_pmax + C2 * (sqq + sq_pmax) * (sqq + sq_pmax);
         if (lane < D_T) qs[lane] = p1[((size_t)b * P1 + i) * D_T + lane];
         tpg_u64 key = INF;
-        if (n <= KM_CAP && lane < n) {
-            const int j = cbuf[(wave * 32 + qq) * KM_CAP + lane];
-            key = knn_pack(knn_dist<D_T>(qs, cb + (size_t)j * D_T, D_T), j);
+        if (j >= 0) {
+            // the canonical sum of knn_dist (knn.hip), the candidate row in registers
+            const float4 *q4 = reinterpret_cast<const float4 *>(qs);
+            float acc = 0.0f;
+#pragma unroll
+            for (int d = 0; d < V4; ++d) {
+                const float4 qv = q4[d];
+                float t;
+                t = qv.x - row[d].x; acc = acc + t * t;
+                t = qv.y - row[d].y; acc = acc + t * t;
+                t = qv.z - row[d].z; acc = acc + t * t;
+                t = qv.w - row[d].w; acc = acc + t * t;
+            }
+            key = knn_pack(acc, j);
         }
-        ks[lane] = key;
+        ks_[lane] = key;
         int rank = 0;
-        for (int s = 0; s < 64; ++s) rank += ks[s] < key ? 1 : 0;
+        const int nk = n <= KM_CAP ? n : 0;
+        for (int s = 0; s < nk; ++s) rank += ks_[s] < key ? 1 : 0;
         const tpg_u64 kth = __ballot(rank == K - 1 && key != INF);
         bool ok = n <= KM_CAP && kth != 0;
         float dk = -1.0f;
@@ -289,5 +376,14 @@ __global__ __launch_bounds__(KM_WAVES * 64, 8 / KM_WAVES) void knn_mfma_kernel(
         } else if (lane == 0) {
             oi[(size_t)i * K] = KM_REDO;
         }
+    };
+    float4 rowA[V4], rowB[V4];
+    int jA, nA, jB, nB;
+    fetch(0, rowA, jA, nA);
+    for (int qq = 0; qq < 32; qq += 2) {
+        fetch(qq + 1, rowB, jB, nB);
+        finish(qq, rowA, jA, nA);
+        fetch(qq + 2, rowA, jA, nA);
+        finish(qq + 1, rowB, jB, nB);
     }
 }
