@@ -46,6 +46,7 @@ def log(msg):
 
 HBM_PEAK_GBPS = 8000.0       # MI355X spec, /opt/skills/guides/MI355X_MICROARCH.md
 MFMA_PEAK_TFLOPS = 2500.0    # dense bf16, same guide (AMD's 5 PF figure is 2:1 sparse)
+MFMA_F32_PEAK_TFLOPS = 157.3  # v_mfma_f32_16x16x4_f32 / 32x32x2: the fp32 vector rate (same guide)
 CONFIG = "cfg2"
 
 
@@ -150,27 +151,32 @@ def roofline_leg(models, clips, steps, sync, amp_dtype):
         line["roofline_streaming"] = roof(sdom, "largest total time among the HBM-streaming hand-written kernels")
     # matrix-core work: the hand-written MFMA kernels and what is left on the library
     mf = {}
-    for grp, names in (("hand_written_mfma", [k for k in hand if k in ("mlp_fwd", "mlp_dgrad", "mlp_wgrad")]),
+    lib_ms = _library_gemm_ms(CONFIG)
+    for grp, names in (("hand_written_mfma", [k for k in hand if k in ("mlp_fwd", "mlp_dgrad", "mlp_wgrad", "knn_mfma")]),
+                       ("hand_written_mfma_f32", [k for k in hand if k in ("small_tail_fwd", "small_tail_bwd")]),
                        ("library_gemm", library)):
         fl = sum(summ[k]["flops_per_launch"] * summ[k]["launches"] for k in names)
         ms = sum(summ[k]["total_ms"] for k in names)
-        if ms > 0 and grp == "hand_written_mfma":
+        if ms > 0 and grp != "library_gemm":
+            peak = MFMA_PEAK_TFLOPS if grp == "hand_written_mfma" else MFMA_F32_PEAK_TFLOPS
             mf[grp] = {"kernels": names, "tflop_per_step": round(fl / steps_f / 1e12, 4), "ms_per_step": round(ms / steps_f, 4),
-                       "achieved_tflops": round(fl / 1e12 / (ms / 1e3), 2),
-                       "frac_of_peak": round(fl / 1e12 / (ms / 1e3) / MFMA_PEAK_TFLOPS, 5)}
+                       "achieved_tflops": round(fl / 1e12 / (ms / 1e3), 2), "peak_tflops": peak,
+                       "frac_of_peak": round(fl / 1e12 / (ms / 1e3) / peak, 5)}
         elif ms > 0:
             # HIP events around a torch GEMM call include the host's enqueue gap in this launch-by-launch leg
             # (20+ us of host time per call): the kernel time comes from the committed rocprofv3 summary
             mf[grp] = {"kernels": names, "tflop_per_step": round(fl / steps_f / 1e12, 4),
                        "launches_per_step": sum(summ[k]["launches"] for k in names) / steps_f,
-                       "ms_per_step": LIBRARY_GEMM_MS, "ms_source": "profiles/%s (Cijk_* rows / executions)" % STATS_FILE,
-                       "achieved_tflops": round(fl / steps_f / 1e12 / (LIBRARY_GEMM_MS / 1e3), 2) if LIBRARY_GEMM_MS else None,
-                       "frac_of_peak": round(fl / steps_f / 1e12 / (LIBRARY_GEMM_MS / 1e3) / MFMA_PEAK_TFLOPS, 5)
-                       if LIBRARY_GEMM_MS else None}
+                       "ms_per_step": lib_ms, "ms_source": "profiles/%s (Cijk_* rows / %d executions)" % (STATS_FILE % CONFIG, STATS_EXECUTIONS),
+                       "achieved_tflops": round(fl / steps_f / 1e12 / (lib_ms / 1e3), 2) if lib_ms else None,
+                       "frac_of_peak": round(fl / steps_f / 1e12 / (lib_ms / 1e3) / MFMA_PEAK_TFLOPS, 5)
+                       if lib_ms else None}
     if mf:
         mf["peak_tflops"] = MFMA_PEAK_TFLOPS
-        mf["note"] = ("bf16 MFMA, dense peak; these contractions run at 43-128 flop/B against a ridge of ~310 flop/B, "
-                      "i.e. they are HBM-bound by design (see roofline_streaming) and the matrix pipe idles")
+        mf["note"] = ("bf16 MFMA, dense peak (the f32 matrix instructions of the 16-channel tails: the 157 TFLOP/s vector "
+                      "rate); the MLP contractions run at 43-128 flop/B against a ridge of ~310 flop/B, i.e. they are "
+                      "HBM-bound by design (see roofline_streaming); knn_mfma counts EXECUTED flops (two sweeps, three "
+                      "split-bf16 products) and is bound by the vector work of its selection")
         line["mfma"] = mf
     table = {k: {"launches_per_step": v["launches"] / steps_f, "ms_per_step": round(v["total_ms"] / steps_f, 4),
                  "avg_us": round(v["avg_us"], 2), "GBps": round(v["gbps"], 1),
@@ -181,22 +187,20 @@ def roofline_leg(models, clips, steps, sync, amp_dtype):
 
 
 PMC_FILE = "r02_pmc_traffic.json"
-STATS_FILE = "r02_a_fused_tails_graph_bf16_kernel_stats.csv"
+STATS_FILE = "r02_final_%s_graph_bf16_kernel_stats.csv"      # % config
+STATS_EXECUTIONS = 15      # `bench.py --config X --steps 10 --warmup 2 --no-extra`: 3 while capturing + 2 + 10
 
 
-def _library_gemm_ms():
-    """hipBLASLt kernel time per step of cfg2 from the committed rocprofv3 summary (15 executions of the step:
-    3 + 2 while capturing, 10 timed), or None when the file is not there."""
+def _library_gemm_ms(config):
+    """hipBLASLt kernel time per step from the committed rocprofv3 summary of this config, or None when the
+    file is not there."""
     import csv
     try:
-        with open(os.path.join(ROOT, "profiles", STATS_FILE)) as fh:
+        with open(os.path.join(ROOT, "profiles", STATS_FILE % config)) as fh:
             tot = sum(float(r["TotalDurationNs"]) for r in csv.DictReader(fh) if r["Name"].startswith("Cijk"))
-        return round(tot / 1e6 / 15, 4)
+        return round(tot / 1e6 / STATS_EXECUTIONS, 4)
     except (OSError, KeyError, ValueError):
         return None
-
-
-LIBRARY_GEMM_MS = _library_gemm_ms()
 
 
 def pmc_traffic(kernel):

@@ -55,11 +55,19 @@ int tpg_knn_f32(const float *p1, const float *p2, const int64_t *len1,
                 const int64_t *len2, int B, int P1, int P2, int D, int K,
                 float r2, float *dist, int64_t *idx, void *stream);
 
+/* Plain 3-D kNN (r2 < 0 form of tpg_knn_f32, D = 3, K <= 64) on the uniform grid of tpg_frnn_grid_f32 with cells of
+ * ~K/2 points: the (2R+1)^3 cells around the query's cell, R grown until the K-th distance lies inside the
+ * covered region.  For the first EdgeConv's search on large clouds (gcn_lib/pointnet/gcn.py:38 at cfg5 /
+ * rollout sizes) and the Chamfer nearest neighbours (loss.py:125-127 at 16384 points).  Bit-identical to
+ * tpg_knn_f32(r2 < 0) incl. the (0, 0) padding; same workspace as tpg_frnn_grid_f32. */
+int tpg_knn_grid_f32(const float *p1, const float *p2, const int64_t *len1, const int64_t *len2, int B,
+                     int P1, int P2, int K, float *dist, int64_t *idx, void *ws, void *stream);
+
 /* Plain kNN (no radius) in D = 32 / 64 feature space, 2 <= K <= 24, 16-byte aligned rows: the path
  * tpg_knn_f32 takes by itself for clouds of >= 2048 points (gcn_lib/pointnet/gcn.py:38,258 at cfg5's
  * 4096-point low-resolution clouds; upsampling_network.py:159-174 rollouts).  A Gram-matrix filter on
- * the f32 matrix cores (v_mfma_f32_32x32x2_f32) rules candidates out with a rigorous rounding bound, the
- * survivors are re-ranked with the canonical distance, and queries the bound cannot settle are redone by
+ * the bf16 matrix cores (split operands, v_mfma_f32_32x32x16_bf16) rules candidates out with a rounding bound,
+ * the survivors are re-ranked with the canonical distance, and queries the bound cannot settle are redone by
  * the exhaustive kernel: the output equals tpg_knn_f32's bit for bit.  redo = 0 (diagnostic) skips that
  * last launch and leaves idx[b][i][0] = -2 on the unsettled queries. */
 int tpg_knn_mfma_f32(const float *p1, const float *p2, const int64_t *len1,

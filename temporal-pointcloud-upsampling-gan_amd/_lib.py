@@ -21,6 +21,7 @@ _L = C.c_longlong
 SIGNATURES = {
     "tpg_knn_f32": [_P, _P, _P, _P, _I, _I, _I, _I, _I, _F, _P, _P, _P],
     "tpg_knn_mfma_f32": [_P, _P, _P, _P, _I, _I, _I, _I, _I, _P, _P, _I, _P],
+    "tpg_knn_grid_f32": [_P, _P, _P, _P, _I, _I, _I, _I, _P, _P, _P, _P],
     "tpg_frnn_grid_f32": [_P, _P, _P, _P, _I, _I, _I, _I, _F, _P, _P, _P, _P],
     "tpg_chamfer_fwd_f32": [_P, _P, _I, _I, _I, _P, _P, _P, _P, _P],
     "tpg_chamfer_bwd_f32": [_P, _P, _I, _I, _I, _P, _P, _P, _P, _P, _P, _P],

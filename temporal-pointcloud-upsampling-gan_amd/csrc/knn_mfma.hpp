@@ -1,4 +1,4 @@
-// Feature-space kNN (D = 32 / 64) on LARGE clouds: Gram-matrix filter on the f32 matrix cores, exact
+// Feature-space kNN (D = 32 / 64) on LARGE clouds: Gram-matrix filter on the bf16 matrix cores, exact
 // re-ranking of the survivors.  Included by knn.hip (inside its anonymous namespace).
 //
 // The exhaustive kernels of knn.hip evaluate the canonical distance sum_d (q_d - p_d)^2 for every pair on
@@ -8,21 +8,29 @@
 //
 //   approximate  d~(q,p) = |y_q|^2 + |y_p|^2 - 2 y_q.y_p ,  y = x - origin (the cloud's first point)
 //
-// comes out of v_mfma_f32_32x32x2_f32 (an exact k-ordered fmaf chain, MI355X_MICROARCH.md) at one matrix
-// instruction per 32 x 32 pairs and 2 dimensions, and |d~ - d_canonical| <= E_q := c_D (|y_q| + max_p|y_p|)^2
-// with c_D = (4 D + 32) 2^-24 (twice the sequential-rounding bound of both sums).  One workgroup owns 256
-// queries (8 waves x 32; the queries stay in registers as the B operand) and sweeps the cloud TWICE through
-// a double-buffered LDS tile of -2 y_p rows:
-//   sweep 1  every lane (query c = lane & 31, rows of its half h = lane >> 5) keeps the 16 smallest of the
-//            per-sub-tile minima of its 16 accumulator rows; tau_q = max over the two lanes of a query of
-//            their 16th value => at least 32 points have d~ <= tau_q (16 distinct sub-tiles per lane);
+// with the product on v_mfma_f32_32x32x16_bf16 from SPLIT operands: t = hi + lo + r, hi = bf16(t),
+// lo = bf16(t - hi), |r| <= 2^-16 |t|; hi.hi + hi.lo + lo.hi leaves out lo.lo and the two residual terms,
+// together <= 6.06 2^-16 |y_q||y_p|.  (A first form on v_mfma_f32_32x32x2_f32 -- exact fp32, five times tighter --
+// was 2-3x slower: the f32 matrix instruction runs at the vector rate and does NOT co-execute with the VALU work
+// of the selection, SQ_VALU_MFMA_COEXEC_CYCLES = 0; the bf16 one costs 7 x 32 cycles per 32 x 32 pairs beside it.)
+// |y_p|^2 enters as a fourth product: three bf16 terms (exact) in the spare words of the LDS row against (1, 1, 1).
+//
+//   |d~ - d_canonical| <= E_q := 2^-13 |y_q| max_p|y_p| + (8 D + 64) 2^-24 (|y_q| + max_p|y_p|)^2
+//
+// One workgroup owns 128 queries (4 waves x 32; the split queries stay in registers as the B operand), two
+// workgroups per CU, and sweeps the cloud TWICE through a double-buffered LDS tile of split -2 y_p rows:
+//   sweep 1  every lane (query c = lane & 31, rows of its half h = lane >> 5) keeps the M smallest of the
+//            minima of its 16 (32 from 4096 points) accumulator rows per entry; tau_q = max over the two lanes of a
+//            query of their M-th value => at least 2 M points have d~ <= tau_q (M distinct row groups per lane);
+//            M = 10 / 14 / 16 by K (K + 8 <= 2 M), 16 from 16384 points;
 //   sweep 2  the same products again; every pair with d~ <= tau_q appends its index to the query's LDS
-//            list (64 slots; ~36 entries expected);
-//   tail     one wave per query: canonical distance of the listed points (the same knn_dist as the
-//            exhaustive kernels), rank by counting over the 64-bit (dist, idx) keys, the first K are the
+//            list (64 slots; ~2.4 M entries expected);
+//   tail     one wave per query: canonical distance of the listed points (the arithmetic of knn_dist), rank
+//            by counting over the 64-bit (dist, idx) keys, the first K are the
 //            answer IF  tau_q - E_q > d_K  (every unlisted point has d~ > tau_q, hence a canonical distance
-//            above d_K: it cannot enter or tie).  Otherwise (duplicate-heavy clouds, list overflow, ragged
-//            tails) the query's first index slot is set to -2 and knn_kernel<D, false, true> -- the
+//            above d_K: it cannot enter or tie).  Otherwise (list overflow, ragged tails, and clouds whose
+//            neighbour spacing is below the rounding bound: thousands of points on a 2-D sheet in feature space)
+//            the query's first index slot is set to -2 and knn_kernel<D, false, true> -- the
 //            exhaustive kernel, one wave per flagged query -- redoes it.  The output is the exhaustive
 //            kernels' output bit for bit in every case; only the time depends on the data.
 #pragma once

@@ -10,6 +10,8 @@ leg has explicitly registered a checker backend with ``register_backend('cpu',
 """
 import ctypes as C
 
+import os
+
 import numpy as np
 import torch
 
@@ -143,6 +145,17 @@ class HipBackend:
     GRID_MIN_POINTS = 1024
     GRID_MIN_PAIRS = 6.0e7
 
+    KNN_GRID_MIN_POINTS = 2048
+
+    def _grid_ws(self, ref, B, P2):
+        need = self.lib.tpg_frnn_grid_workspace_bytes(B, P2)
+        key = ("frnn", ref.device, torch.cuda.current_stream(ref.device).cuda_stream)
+        ws = self._ws.get(key)
+        if ws is None or ws.numel() < need:
+            ws = torch.empty(need, dtype=torch.uint8, device=ref.device)
+            self._ws[key] = ws
+        return ws
+
     def knn(self, p1, p2, len1, len2, K, r2, r=None):
         B, P1, D = p1.shape
         P2 = p2.shape[1]
@@ -150,19 +163,24 @@ class HipBackend:
         idx = torch.empty((B, P1, K), dtype=torch.int64, device=p1.device)
         if (r is not None and r2 is not None and D == 3 and K <= 64 and P2 >= self.GRID_MIN_POINTS
                 and float(B) * P1 * P2 >= self.GRID_MIN_PAIRS and float(r) > 0):
-            need = self.lib.tpg_frnn_grid_workspace_bytes(B, P2)
-            key = ("frnn", p1.device, torch.cuda.current_stream(p1.device).cuda_stream)
-            ws = self._ws.get(key)
-            if ws is None or ws.numel() < need:
-                ws = torch.empty(need, dtype=torch.uint8, device=p1.device)
-                self._ws[key] = ws
             self._call("tpg_frnn_grid_f32", "frnn_grid", 4 * B * D * (P1 + P2) + 12 * B * P1 * K, p1,
                        _ptr(p1), _ptr(p2), _ptr(len1), _ptr(len2), B, P1, P2, K, float(np.float32(r)), _ptr(dist),
-                       _ptr(idx), _ptr(ws))
+                       _ptr(idx), _ptr(self._grid_ws(p1, B, P2)))
             return dist, idx
-        self._call("tpg_knn_f32", "knn", 4 * B * D * (P1 + P2) + 12 * B * P1 * K, p1,
+        if (r2 is None and D == 3 and K <= 64 and P2 >= self.KNN_GRID_MIN_POINTS
+                and float(B) * P1 * P2 >= self.GRID_MIN_PAIRS):
+            # plain 3-D kNN on the uniform grid (first EdgeConv at cfg5 / rollout sizes, Chamfer at 16384 points):
+            # measured (tools/tune_frnn.py) B = 40, 4096 points, K = 20: 431 us exhaustive
+            self._call("tpg_knn_grid_f32", "knn_grid", 4 * B * D * (P1 + P2) + 12 * B * P1 * K, p1,
+                       _ptr(p1), _ptr(p2), _ptr(len1), _ptr(len2), B, P1, P2, K, _ptr(dist), _ptr(idx),
+                       _ptr(self._grid_ws(p1, B, P2)))
+            return dist, idx
+        # (the library takes the matrix-core filter by itself under exactly this condition, csrc/knn.hip: the name
+        # and the executed flops -- two sweeps, three split products -- are for the per-kernel timer only)
+        mfma = r2 is None and D in (32, 64) and 1 < K <= 24 and P2 >= 2048 and os.environ.get("TPG_KNN_MFMA", "1")[:1] != "0"
+        self._call("tpg_knn_f32", "knn_mfma" if mfma else "knn", 4 * B * D * (P1 + P2) + 12 * B * P1 * K, p1,
                    _ptr(p1), _ptr(p2), _ptr(len1), _ptr(len2), B, P1, P2, D, K,
-                   -1.0 if r2 is None else r2, _ptr(dist), _ptr(idx))
+                   -1.0 if r2 is None else r2, _ptr(dist), _ptr(idx), flops=12.0 * B * P1 * P2 * D if mfma else 0)
         return dist, idx
 
     def knn_mfma(self, p1, p2, len1, len2, K, redo=True):
@@ -175,7 +193,7 @@ class HipBackend:
         idx = torch.zeros((B, P1, K), dtype=torch.int64, device=p1.device)
         self._call("tpg_knn_mfma_f32", "knn_mfma", 4 * B * D * (P1 + P2) + 12 * B * P1 * K, p1,
                    _ptr(p1), _ptr(p2), _ptr(len1), _ptr(len2), B, P1, P2, D, K, _ptr(dist), _ptr(idx), 1 if redo else 0,
-                   flops=2.0 * 2 * B * P1 * P2 * D)
+                   flops=12.0 * B * P1 * P2 * D)
 
         return dist, idx
 
@@ -195,6 +213,11 @@ class HipBackend:
         M = tgt.shape[1]
         d1 = torch.empty((B, N), dtype=torch.float32, device=src.device)
         i1 = torch.empty((B, N), dtype=torch.int64, device=src.device)
+        if min(N, M) >= self.KNN_GRID_MIN_POINTS and float(B) * N * M >= self.GRID_MIN_PAIRS:
+            # both directions on the uniform grid (loss.py:125-127 at cfg5's 16384-point clouds: 2.9 ms exhaustive)
+            d1, i1 = self.knn(src, tgt, None, None, 1, None)
+            d2, i2 = self.knn(tgt, src, None, None, 1, None)
+            return d1.view(B, N), i1.view(B, N), d2.view(B, M), i2.view(B, M)
         d2 = torch.empty((B, M), dtype=torch.float32, device=src.device)
         i2 = torch.empty((B, M), dtype=torch.int64, device=src.device)
         self._call("tpg_chamfer_fwd_f32", "chamfer_fwd", 24 * B * (N + M), src,

@@ -628,6 +628,64 @@ def test_frnn_grid_bit_exact(hip, B, P1, P2, K, r):
     assert np.array_equal(d.cpu().numpy(), rd)
 
 
+def _knn_grid(hip, p1, p2, K, len1=None, len2=None):
+    old = hip.KNN_GRID_MIN_POINTS, hip.GRID_MIN_PAIRS
+    hip.KNN_GRID_MIN_POINTS, hip.GRID_MIN_PAIRS = 1, 0.0         # force the grid whatever the size
+    try:
+        l1 = None if len1 is None else dev(np.asarray(len1, np.int64))
+        l2 = None if len2 is None else dev(np.asarray(len2, np.int64))
+        return hip.knn(dev(p1), dev(p2), l1, l2, K, None)
+    finally:
+        hip.KNN_GRID_MIN_POINTS, hip.GRID_MIN_PAIRS = old
+
+
+@pytest.mark.parametrize("B,P1,P2,K", [
+    (2, 4096, 4096, 20), (1, 16384, 16384, 20), (2, 4096, 4096, 1), (1, 700, 16384, 1), (1, 2000, 65536, 32),
+    (3, 256, 256, 32), (1, 100, 300, 8), (1, 64, 64, 64), (2, 33, 77, 5), (1, 50, 20, 30)])
+def test_knn_grid_bit_exact(hip, B, P1, P2, K):
+    """Plain 3-D kNN on the uniform grid (growing cell blocks) against the oracle: indices, distances, (0, 0) padding
+    when the cloud has fewer than K points; duplicates, queries outside the box."""
+    rng = np.random.default_rng(P1 + 3 * P2 + K)
+    p2 = fluid(rng, B, P2)
+    p1 = p2.copy() if P1 == P2 else fluid(rng, B, P1, scale=0.3 * max(1.0, (P2 / 4096.0) ** (1.0 / 3.0)))
+    if P2 > 20:
+        p2[0, 5] = p2[0, 7]
+        if P1 == P2:
+            p1 = p2.copy()
+    d, i = _knn_grid(hip, p1, p2, K)
+    rd, ri = R.knn(p1, p2, K)
+    assert np.array_equal(i.cpu().numpy(), ri)
+    assert np.array_equal(d.cpu().numpy(), rd)
+
+
+def test_knn_grid_ragged_dummies_flat_and_far(hip):
+    """lengths, 999-dummies (the box grows and with it the cells: blocks must grow too), queries far outside the
+    box, a cloud of identical points, a flat cloud (z = 0), and the size switch of the public entries incl. Chamfer."""
+    import tpgan_amd.ops as ops
+    rng = np.random.default_rng(5)
+    p2 = fluid(rng, 4, 3000)
+    p1 = fluid(rng, 4, 700)
+    p2[1, 2500:] = 999.0
+    p1[0, :5] = 50.0
+    p2[2, :] = p2[2, 0]
+    p2[3, :, 2] = 0.0
+    l1, l2 = [700, 650, 10, 700], [3000, 2800, 3000, 7]
+    d, i = _knn_grid(hip, p1, p2, 16, len1=l1, len2=l2)
+    rd, ri = R.knn(p1, p2, 16, lengths1=l1, lengths2=l2)
+    assert np.array_equal(i.cpu().numpy(), ri) and np.array_equal(d.cpu().numpy(), rd)
+    big = fluid(rng, 2, 8192)
+    assert 2 * 8192 * 8192 >= hip.GRID_MIN_PAIRS and 8192 >= hip.KNN_GRID_MIN_POINTS
+    dd, ii = ops.neighbour_search(dev(big), dev(big), 20)
+    rd, ri = R.knn(big, big, 20)
+    assert np.array_equal(ii.cpu().numpy(), ri) and np.array_equal(dd.cpu().numpy(), rd)
+    other = big + rng.normal(0, 0.01, big.shape).astype(np.float32)
+    d1, i1, d2, i2 = hip.chamfer_fwd(dev(big), dev(other))
+    r1, j1 = R.knn(big, other, 1)
+    r2, j2 = R.knn(other, big, 1)
+    assert np.array_equal(i1.cpu().numpy(), j1[..., 0]) and np.array_equal(d1.cpu().numpy(), r1[..., 0])
+    assert np.array_equal(i2.cpu().numpy(), j2[..., 0]) and np.array_equal(d2.cpu().numpy(), r2[..., 0])
+
+
 def test_frnn_grid_ragged_dummies_and_far_queries(hip):
     """lengths1 / lengths2, 999-dummies in the searched cloud (the box grows, the cells with it: still
     exact), queries far outside the box (no neighbour: all -1), a degenerate cloud of identical points."""
