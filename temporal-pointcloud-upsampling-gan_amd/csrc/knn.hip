@@ -72,7 +72,7 @@ __device__ __forceinline__ float knn_dist(const float *__restrict__ qs,
 
 constexpr long long KM_REDO_MARK = -2;   // knn_mfma.hpp: first index slot of a query the filter could not settle
 
-template <int D_T, bool RADIUS, bool REDO = false>
+template <int D_T, bool RADIUS>
 __global__ __launch_bounds__(KNN_WAVES * 64) void knn_kernel(
     const float *__restrict__ p1, const float *__restrict__ p2,
     const int64_t *__restrict__ len1, const int64_t *__restrict__ len2, int B, int P1, int P2,
@@ -99,7 +99,6 @@ __global__ __launch_bounds__(KNN_WAVES * 64) void knn_kernel(
     }
     __syncthreads();
     if (!valid) return;
-    if (REDO && idx[q * K] != KM_REDO_MARK) return;       // only the queries the matrix-core filter left open
 
     const float pad_d = RADIUS ? -1.0f : 0.0f;
     const long long pad_i = RADIUS ? -1 : 0;
@@ -231,6 +230,53 @@ __global__ __launch_bounds__(KNN_WAVES * 64) void knn_tile_kernel(
     }
 }
 
+// The queries the matrix-core filter left open (first index slot == KM_REDO_MARK), exhaustively: a workgroup looks
+// at 4 consecutive queries and gives EVERY open one all four of its waves -- each wave scans a quarter of the cloud
+// into its own K-best list, wave 0 merges the four lists (4 x 64 keys through the same rank merge).  Open queries
+// are a handful per cloud and sit in different workgroups: the launch lasts one quarter-scan, not one scan.
+template <int D_T>
+__global__ __launch_bounds__(KNN_WAVES * 64) void knn_redo_kernel(
+    const float *__restrict__ p1, const float *__restrict__ p2, const int64_t *__restrict__ len1,
+    const int64_t *__restrict__ len2, int P1, int P2, int K, float *__restrict__ dist, int64_t *__restrict__ idx) {
+    __shared__ __attribute__((aligned(16))) float qs[D_T];
+    __shared__ tpg_u64 slots[KNN_WAVES * 64];
+    __shared__ tpg_u64 lists[KNN_WAVES * 64];
+    const int lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int b = blockIdx.y;
+    const int n1 = len1 ? (int)len1[b] : P1;
+    const int n2 = len2 ? min((int)len2[b], P2) : P2;
+    const float *cbase = p2 + (size_t)b * P2 * D_T;
+    const tpg_u64 INF = ~0ull;
+    for (int u = 0; u < KNN_WAVES; ++u) {
+        const int i = blockIdx.x * KNN_WAVES + u;
+        if (i >= P1) break;                                            // (uniform over the workgroup)
+        const size_t q = (size_t)b * P1 + i;
+        if (idx[q * K] != KM_REDO_MARK) continue;                      // (uniform: every thread reads the same slot)
+        __syncthreads();                                               // the previous query's LDS is free
+        if (threadIdx.x < D_T) qs[threadIdx.x] = p1[q * D_T + threadIdx.x];
+        __syncthreads();
+        tpg_u64 best = INF, thr = INF;
+        if (i < n1)
+            for (int base = wave * 64; base < n2; base += KNN_WAVES * 64) {
+                const int j = base + lane;
+                const tpg_u64 key = j < n2 ? knn_pack(knn_dist<D_T>(qs, cbase + (size_t)j * D_T, D_T), j) : INF;
+                tpg_knn_merge(best, thr, key, K, lane, slots + wave * 64);
+            }
+        lists[wave * 64 + lane] = lane < K ? best : INF;
+        __syncthreads();
+        if (wave == 0) {
+            best = INF;
+            thr = INF;
+            for (int w = 0; w < KNN_WAVES; ++w) tpg_knn_merge(best, thr, lists[w * 64 + lane], K, lane, slots);
+            if (lane < K) {
+                if (best == INF) { dist[q * K + lane] = 0.0f; idx[q * K + lane] = 0; }
+                else { dist[q * K + lane] = __uint_as_float((unsigned)(best >> 32)); idx[q * K + lane] = (long long)(unsigned)best; }
+            }
+        }
+    }
+}
+
 #include "knn_mfma.hpp"
 
 #ifndef TPG_KNN_MFMA_MIN_POINTS
@@ -257,8 +303,7 @@ int knn_mfma_launch_m(const float *p1, const float *p2, const int64_t *len1, con
     TPG_RETURN_IF_LAUNCH_FAILED();
     if (redo) {
         const dim3 rg((unsigned)((P1 + KNN_WAVES - 1) / KNN_WAVES), (unsigned)B);
-        hipLaunchKernelGGL((knn_kernel<D_T, false, true>), rg, dim3(KNN_WAVES * 64), sizeof(float) * KNN_WAVES * D_T, st, p1, p2,
-                           len1, len2, B, P1, P2, D_T, K, -1.0f, dist, idx);
+        hipLaunchKernelGGL((knn_redo_kernel<D_T>), rg, dim3(KNN_WAVES * 64), 0, st, p1, p2, len1, len2, P1, P2, K, dist, idx);
         TPG_RETURN_IF_LAUNCH_FAILED();
     }
     return TPG_OK;

@@ -30,8 +30,8 @@
 //            answer IF  tau_q - E_q > d_K  (every unlisted point has d~ > tau_q, hence a canonical distance
 //            above d_K: it cannot enter or tie).  Otherwise (list overflow, ragged tails, and clouds whose
 //            neighbour spacing is below the rounding bound: thousands of points on a 2-D sheet in feature space)
-//            the query's first index slot is set to -2 and knn_kernel<D, false, true> -- the
-//            exhaustive kernel, one wave per flagged query -- redoes it.  The output is the exhaustive
+//            the query's first index slot is set to -2 and knn_redo_kernel (knn.hip: the
+//            exhaustive scan, four waves per flagged query) redoes it.  The output is the exhaustive
 //            kernels' output bit for bit in every case; only the time depends on the data.
 #pragma once
 
