@@ -24,6 +24,10 @@ KERNELS = {  # bench op name -> substring of the kernel symbol
     "mlp_dgrad": "mlp_dgrad_kernel",
     "mlp_wgrad": "mlp_wgrad_kernel",
     "mlp_bn_bwd_apply": "mlp_bn_bwd_apply_kernel",
+    "small_tail_fwd": "small_tail_fwd_kernel",
+    "small_tail_bwd": "small_tail_bwd_kernel",
+    "knn_mfma": "knn_mfma_kernel",
+    "knn_grid": "fg_knn_kernel",
     "frnn_grid": "fg_query_kernel",
     "rowcombine_fwd": "rowcombine_fwd_kernel",
     "rowcombine_bwd": "rowcombine_bwd_",             # thread- and wave-per-row forms
