@@ -129,10 +129,20 @@ def roofline_leg(models, clips, steps, sync, amp_dtype):
 
     def roof(name, selection):
         d = summ[name]
+        if name == "knn_mfma":
+            # the matrix-core kNN filter streams a cache-resident cloud: priced against the matrix peak on its EXECUTED
+            # flops (two sweeps, three split-bf16 products); what bounds it is the vector work of the selection
+            return {"bound": "mfma", "kernel": name, "achieved": round(d["tflops"], 2), "peak": MFMA_PEAK_TFLOPS,
+                    "unit": "TFLOP/s", "frac": round(d["tflops"] / MFMA_PEAK_TFLOPS, 6), "traffic": None,
+                    "avg_launch_us": round(d["avg_us"], 2), "launches_per_step": d["launches"] / steps_f,
+                    "ms_per_step": round(d["total_ms"] / steps_f, 4),
+                    "executed_flops_per_launch": int(d["flops_per_launch"]), "selection": selection,
+                    "note": "split-bf16 Gram filter + exact re-rank (DESIGN.md section 4d): ~115 vector instructions per 32 x 32 "
+                            "pairs and sweep bound it, the 7 matrix instructions co-execute; launch time includes the fallback kernel"}
         return {"bound": "hbm", "kernel": name, "achieved": round(d["gbps"], 2), "peak": HBM_PEAK_GBPS,
                 "unit": "GB/s", "frac": round(d["gbps"] / HBM_PEAK_GBPS, 6), "traffic": pmc_traffic(name),
-                "traffic_source": "profiles/%s (rocprofv3 PMC passes of the same step body; not re-measured in this run)"
-                                  % PMC_FILE,
+                "traffic_source": "profiles/%s (rocprofv3 PMC passes of the cfg2 step body, average over the kernel's launches; "
+                                  "not re-measured in this run; null for other configs)" % PMC_FILE,
                 "avg_launch_us": round(d["avg_us"], 2), "launches_per_step": d["launches"] / steps_f,
                 "ms_per_step": round(d["total_ms"] / steps_f, 4),
                 "algorithmic_bytes_per_launch": int(d["bytes_per_launch"]), "selection": selection}
@@ -206,6 +216,8 @@ def _library_gemm_ms(config):
 def pmc_traffic(kernel):
     """HBM bytes per launch of `kernel` from the committed rocprofv3 PMC passes (profiles/), with the
     gfx950 FETCH_SIZE x2 correction for wide coalesced reads; None when no PMC file is present."""
+    if CONFIG != "cfg2":
+        return None                      # the committed PMC passes are of the cfg2 step body
     path = os.path.join(ROOT, "profiles", PMC_FILE)
     try:
         with open(path) as fh:
