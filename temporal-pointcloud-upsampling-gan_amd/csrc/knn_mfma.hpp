@@ -6,7 +6,7 @@
 // 30 ms on a 65536-point rollout scene (upsampling_network.py:159-174) -- 97 % of a rollout frame.  The
 // neighbour LIST is what must be bit-exact against the oracle, not the way candidates are ruled out:
 //
-//   approximate  d~(q,p) = |y_q|^2 + |y_p|^2 - 2 y_q.y_p ,  y = x - origin (the cloud's first point)
+//   approximate  d~(q,p) = |y_q|^2 + |y_p|^2 - 2 y_q.y_p ,  y = x - origin (the mean of the cloud's first tile of points)
 //
 // with the product on v_mfma_f32_32x32x16_bf16 from SPLIT operands: t = hi + lo + r, hi = bf16(t),
 // lo = bf16(t - hi), |r| <= 2^-16 |t|; hi.hi + hi.lo + lo.hi leaves out lo.lo and the two residual terms,
@@ -124,7 +124,20 @@ __global__ __launch_bounds__(KM_WAVES * 64, 8 / KM_WAVES) void knn_mfma_kernel(
     }
     const float *cb = p2 + (size_t)b * P2 * D_T;
     for (int t = tid; t < KM_Q; t += KM_WAVES * 64) cnt[t] = 0;
-    if (tid < D_T) org[tid] = cb[tid];
+    // origin = mean of the cloud's first KM_TP points (a sample of the cloud in index order: near its centre, where the
+    // first point alone may sit on the rim and double every |y|, i.e. quadruple the bound E_q); summed in a fixed order
+    {
+        float *raw = reinterpret_cast<float *>(tile);                  // [KM_TP][D_T] floats fit the first tile buffer
+        const int rows0 = min(n2, KM_TP);
+        for (int t = tid; t < rows0 * (D_T / 4); t += KM_WAVES * 64)
+            reinterpret_cast<float4 *>(raw)[t] = reinterpret_cast<const float4 *>(cb)[t];
+        __syncthreads();
+        if (tid < D_T) {
+            float a = 0.0f;
+            for (int r = 0; r < rows0; ++r) a += raw[r * D_T + tid];
+            org[tid] = a / (float)rows0;
+        }
+    }
     if (tid == 0) *pmax = 0u;
     __syncthreads();
 
