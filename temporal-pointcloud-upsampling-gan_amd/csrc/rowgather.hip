@@ -21,6 +21,8 @@
 // fp32 in registers, one rounding on store).
 #include <hip/hip_bf16.h>
 
+#include <cstdlib>
+
 #include "tpg_common.hpp"
 
 namespace {
@@ -94,14 +96,18 @@ template <typename TA, typename TB> struct Elems {
 template <typename TI, typename TO, int MODE>
 __global__ __launch_bounds__(256) void rowcombine_fwd_kernel(
     const TI *__restrict__ U, const TI *__restrict__ QE, const int32_t *__restrict__ idx, int N, int S,
-    int K, int C, float slope, TO *__restrict__ out, unsigned total) {
+    int K, int C, float slope, TO *__restrict__ out, unsigned total, int xcd_order) {
     constexpr int NE = Elems<TI, TO>::NE;
     constexpr int UF = TPG_RC_FWD_U;
     using In = RowIO<TI, NE>;
     using Out = RowIO<TO, NE>;
     const unsigned cpr = (unsigned)C / NE;  // 16-byte chunks per row
     const unsigned stride = gridDim.x * 256u;
-    unsigned t = blockIdx.x * 256u + threadIdx.x;
+    // consecutive workgroup ids land on the 8 XCDs in turn: with the plain order every XCD's L2 fetches every
+    // cloud's source table (PMC, round 1: 1.5x the algorithmic bytes).  xcd_order (grid a multiple of 8): XCD x
+    // takes the x-th eighth of each pass over the output, i.e. whole clouds.
+    const unsigned lb = xcd_order ? (blockIdx.x & 7u) * (gridDim.x >> 3) + (blockIdx.x >> 3) : blockIdx.x;
+    unsigned t = lb * 256u + threadIdx.x;
     auto one = [&](unsigned tt) {
         const unsigned row = tt / cpr;            // flat (b,s,k)
         const unsigned col = (tt - row * cpr) * NE;
@@ -474,15 +480,19 @@ int fwd_go(const void *U, const void *QE, const int32_t *idx, int mode, int B, i
     const unsigned long long total64 = (unsigned long long)B * S * K * (C / NE);
     if (total64 >= 0x7fffffffULL) return TPG_ERR_ARG;
     const unsigned total = (unsigned)total64;
-    const dim3 g(grid_for(total, TPG_RC_FWD_U, TPG_RC_FWD_CAP)), blk(256);
+    static const bool xcd_on = [] { const char *e = getenv("TPG_RC_XCD"); return !(e && e[0] == '0'); }();   // A/B switch
+    unsigned nb = grid_for(total, TPG_RC_FWD_U, TPG_RC_FWD_CAP);
+    const int xo = xcd_on && nb >= 64u;
+    if (xo) nb = (nb + 7u) & ~7u;
+    const dim3 g(nb), blk(256);
     const TI *u = static_cast<const TI *>(U), *q = static_cast<const TI *>(QE);
     TO *o = static_cast<TO *>(out);
     if (mode == MODE_GATHER)
-        hipLaunchKernelGGL((rowcombine_fwd_kernel<TI, TO, MODE_GATHER>), g, blk, 0, st, u, q, idx, N, S, K, C, slope, o, total);
+        hipLaunchKernelGGL((rowcombine_fwd_kernel<TI, TO, MODE_GATHER>), g, blk, 0, st, u, q, idx, N, S, K, C, slope, o, total, xo);
     else if (mode == MODE_SUB)
-        hipLaunchKernelGGL((rowcombine_fwd_kernel<TI, TO, MODE_SUB>), g, blk, 0, st, u, q, idx, N, S, K, C, slope, o, total);
+        hipLaunchKernelGGL((rowcombine_fwd_kernel<TI, TO, MODE_SUB>), g, blk, 0, st, u, q, idx, N, S, K, C, slope, o, total, xo);
     else
-        hipLaunchKernelGGL((rowcombine_fwd_kernel<TI, TO, MODE_EDGE>), g, blk, 0, st, u, q, idx, N, S, K, C, slope, o, total);
+        hipLaunchKernelGGL((rowcombine_fwd_kernel<TI, TO, MODE_EDGE>), g, blk, 0, st, u, q, idx, N, S, K, C, slope, o, total, xo);
     return TPG_OK;
 }
 
