@@ -106,6 +106,7 @@ __global__ __launch_bounds__(SN_THREADS) void spectral_norm_bwd_kernel(
 // flow-embedding pair), and each call advances (u, v) by one power iteration and uses its own
 // W / sigma.  desc[m] = {W, u, v, R, Cn, uses, out_off}: for use t the kernel writes, at
 // out + out_off + t * stride(R, Cn):  W/sigma_t (R*Cn) | u_t (R) | v_t (Cn) | sigma_t (1).
+constexpr int SN_CB = 9;        // 64-column blocks a lane covers in the one-pass W^T u: weights of up to 576 columns
 struct SnDesc {
     const float *W;
     float *u;
@@ -136,19 +137,36 @@ __global__ __launch_bounds__(SN_THREADS) void spectral_norm_multi_fwd_kernel(con
             // atomic per (wave, column) summed in arrival order: u, v, sigma -- hence every weight of
             // the step -- differed in the last bit from run to run, which the step then amplifies;
             // tests/test_graph_gpu.py compares a replay with its own body bit for bit)
-            float *slab = scratch + 16;                     // [16 waves][64 columns]
-            for (int j0 = 0; j0 < Cn; j0 += 64) {
-                const int j = j0 + lane;
-                float acc = 0.0f;
-                if (j < Cn)
-                    for (int i = wave; i < R; i += SN_THREADS / 64) acc += W[(size_t)i * Cn + j] * su[i];
-                slab[wave * 64 + lane] = acc;
+            // ... in ONE pass over the matrix: a lane keeps the partial sums of its columns lane, lane + 64, ... in
+            // registers (SN_CB of them), the slab holds all Cn columns of all 16 waves, and the wave-ordered sums run on
+            // every thread, not on wave 0 alone (a pass per 64-column block with two barriers each cost 9 x that for
+            // the 515-column weights: 30 us per use, 474 us for the 16 chained uses of cfg4's temporal discriminator)
+            float *slab = scratch + 16;                     // [16 waves][min(Cn, 64 SN_CB) columns]
+            const int SW = Cn < 64 * SN_CB ? Cn : 64 * SN_CB;
+            for (int jb = 0; jb < Cn; jb += 64 * SN_CB) {    // (one trip for every weight of the discriminators)
+                float acc[SN_CB];
+#pragma unroll
+                for (int c = 0; c < SN_CB; ++c) acc[c] = 0.0f;
+                for (int i = wave; i < R; i += SN_THREADS / 64) {
+                    const float ui = su[i];
+                    const float *wr = W + (size_t)i * Cn + jb;
+#pragma unroll
+                    for (int c = 0; c < SN_CB; ++c) {
+                        const int j = lane + 64 * c;
+                        if (jb + j < Cn) acc[c] += wr[j] * ui;
+                    }
+                }
+#pragma unroll
+                for (int c = 0; c < SN_CB; ++c) {
+                    const int j = lane + 64 * c;
+                    if (jb + j < Cn) slab[wave * SW + j] = acc[c];
+                }
                 __syncthreads();
-                if (wave == 0 && j < Cn) {
+                for (int j = tid; j < SW && jb + j < Cn; j += SN_THREADS) {
                     float t = 0.0f;
 #pragma unroll
-                    for (int w = 0; w < SN_THREADS / 64; ++w) t += slab[w * 64 + lane];
-                    sv[j] = t;
+                    for (int w = 0; w < SN_THREADS / 64; ++w) t += slab[w * SW + j];
+                    sv[jb + j] = t;
                 }
                 __syncthreads();
             }
@@ -268,8 +286,9 @@ extern "C" int tpg_spectral_norm_multi_fwd(const void *desc, int M, int max_rc, 
                                            void *stream) {
     if (M < 0 || !desc || !out) return TPG_ERR_ARG;
     if (M == 0) return TPG_OK;
-    const size_t smem = sizeof(float) * ((size_t)max_rc + 64 + 16 * 64);     // u | v | scratch | column slab
-    if (smem > 48 * 1024) return TPG_ERR_UNSUPPORTED;
+    // u | v | scratch | column slab (16 waves x Cn <= max_rc columns)
+    const size_t smem = sizeof(float) * ((size_t)max_rc + 64 + 16 * (size_t)(max_rc < 64 * SN_CB ? max_rc : 64 * SN_CB));
+    if (smem > 64 * 1024) return TPG_ERR_UNSUPPORTED;
     hipLaunchKernelGGL(spectral_norm_multi_fwd_kernel, dim3(M), dim3(SN_THREADS), smem, tpg_stream(stream),
                        static_cast<const SnDesc *>(desc), out, iterate, eps);
     TPG_RETURN_IF_LAUNCH_FAILED();
