@@ -146,6 +146,7 @@ class HipBackend:
     GRID_MIN_PAIRS = 6.0e7
 
     KNN_GRID_MIN_POINTS = 2048
+    CHAMFER_GRID_MIN_POINTS = 8192
 
     def _grid_ws(self, ref, B, P2):
         need = self.lib.tpg_frnn_grid_workspace_bytes(B, P2)
@@ -213,8 +214,10 @@ class HipBackend:
         M = tgt.shape[1]
         d1 = torch.empty((B, N), dtype=torch.float32, device=src.device)
         i1 = torch.empty((B, N), dtype=torch.int64, device=src.device)
-        if min(N, M) >= self.KNN_GRID_MIN_POINTS and float(B) * N * M >= self.GRID_MIN_PAIRS:
-            # both directions on the uniform grid (loss.py:125-127 at cfg5's 16384-point clouds: 2.9 ms exhaustive)
+        if min(N, M) >= self.CHAMFER_GRID_MIN_POINTS and float(B) * N * M >= self.GRID_MIN_PAIRS:
+            # both directions on the uniform grid (loss.py:125-127 at cfg5's 16384-point clouds: 2.9 ms exhaustive,
+            # 0.3 ms on the grid; at 4096 points the two exhaustive K = 1 launches (0.17 ms) cost what the grid's
+            # twelve do, so the switch sits above that size)
             d1, i1 = self.knn(src, tgt, None, None, 1, None)
             d2, i2 = self.knn(tgt, src, None, None, 1, None)
             return d1.view(B, N), i1.view(B, N), d2.view(B, M), i2.view(B, M)

@@ -674,7 +674,7 @@ def test_knn_grid_ragged_dummies_flat_and_far(hip):
     rd, ri = R.knn(p1, p2, 16, lengths1=l1, lengths2=l2)
     assert np.array_equal(i.cpu().numpy(), ri) and np.array_equal(d.cpu().numpy(), rd)
     big = fluid(rng, 2, 8192)
-    assert 2 * 8192 * 8192 >= hip.GRID_MIN_PAIRS and 8192 >= hip.KNN_GRID_MIN_POINTS
+    assert 2 * 8192 * 8192 >= hip.GRID_MIN_PAIRS and 8192 >= hip.KNN_GRID_MIN_POINTS and 8192 >= hip.CHAMFER_GRID_MIN_POINTS
     dd, ii = ops.neighbour_search(dev(big), dev(big), 20)
     rd, ri = R.knn(big, big, 20)
     assert np.array_equal(ii.cpu().numpy(), ri) and np.array_equal(dd.cpu().numpy(), rd)
