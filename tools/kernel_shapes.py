@@ -14,7 +14,8 @@ import torch                                                             # noqa:
 
 prefixes = tuple(sys.argv[1:]) or ("rowbn_", "rowcombine_")
 sys.argv = [sys.argv[0]]
-import bench                                                             # noqa: E402
+import bench
+from tpgan_amd.synthetic import fluid_clip  # noqa: E402
 from tpgan_amd import ops                                                # noqa: E402
 from tpgan_amd.gan_step_graph import GraphedFluidStep                    # noqa: E402
 
@@ -30,7 +31,7 @@ def main():
     dev = torch.device("cuda", 0)
     np.random.seed(0)
     G, Ds, Dt, opts = bench.build(dev, capturable=True)
-    clips = [bench.fluid_clip(8, 4096, 8, 3, seed=s, device=dev) for s in range(2)]
+    clips = [fluid_clip(8, 4096, 8, 3, seed=s, device=dev) for s in range(2)]
     step = GraphedFluidStep(G, Ds, Dt, opts, bench.OPT, clips[0][0], clips[0][1], 1.0, torch.bfloat16, None)
     step._load(*clips[1])
     step._run_eager(True)

@@ -12,7 +12,8 @@ import numpy as np                                                       # noqa:
 import torch                                                             # noqa: E402
 
 sys.argv = [sys.argv[0]]
-import bench                                                             # noqa: E402
+import bench
+from tpgan_amd.synthetic import fluid_clip  # noqa: E402
 from tpgan_amd import ops                                                # noqa: E402
 from tpgan_amd.gan_step_graph import GraphedFluidStep                    # noqa: E402
 
@@ -42,7 +43,7 @@ def main():
     dev = torch.device("cuda", 0)
     np.random.seed(0)
     G, Ds, Dt, opts = bench.build(dev, capturable=True)
-    clips = [bench.fluid_clip(8, 4096, 8, 3, seed=s, device=dev) for s in range(2)]
+    clips = [fluid_clip(8, 4096, 8, 3, seed=s, device=dev) for s in range(2)]
     step = GraphedFluidStep(G, Ds, Dt, opts, bench.OPT, clips[0][0], clips[0][1], 1.0, torch.bfloat16, None)
     step._load(*clips[1])
     step._run_eager(True)
