@@ -130,7 +130,15 @@ class HipBackend:
     def __init__(self):
         self.lib = _lib.load()
         self._ws = {}
+        self._ws_retired = []   # outgrown workspaces: captured graphs may still hold their addresses
         self._sn_plans = {}
+
+    def _retire(self, ws):
+        """A workspace that is being replaced by a larger one stays allocated: a hipGraph captured earlier has its
+        address baked in, and replaying that graph after the tensor went back to the allocator would scribble on
+        whoever got the memory next.  (Sizes grow monotonically per (kind, stream): a handful of buffers at most.)"""
+        if ws is not None:
+            self._ws_retired.append(ws)
 
     def _call(self, symbol, op, nbytes, ref, *args, flops=0):
         fn = getattr(self.lib, symbol)
@@ -153,6 +161,7 @@ class HipBackend:
         key = ("frnn", ref.device, torch.cuda.current_stream(ref.device).cuda_stream)
         ws = self._ws.get(key)
         if ws is None or ws.numel() < need:
+            self._retire(ws)
             ws = torch.empty(need, dtype=torch.uint8, device=ref.device)
             self._ws[key] = ws
         return ws
@@ -352,6 +361,7 @@ class HipBackend:
         ws = self._ws.get(key)
         need = self.lib.tpg_rowbn_workspace_bytes(max(C_, 256), max(nseg, 1)) // 4
         if ws is None or ws.numel() < need:
+            self._retire(ws)
             ws = torch.zeros(need, dtype=torch.float32, device=x.device)
             self._ws[key] = ws
         return ws
@@ -408,6 +418,7 @@ class HipBackend:
         ws = self._ws.get(key)
         need = self.lib.tpg_mlp_workspace_bytes(max(C_, 256), max(nseg, 1)) // 4
         if ws is None or ws.numel() < need:
+            self._retire(ws)
             ws = torch.zeros(need, dtype=torch.float32, device=x.device)
             self._ws[key] = ws
         return ws
@@ -520,6 +531,7 @@ class HipBackend:
         key = ("wgrad", x_out.device, torch.cuda.current_stream(x_out.device).cuda_stream)
         ws = self._ws.get(key)
         if ws is None or ws.numel() < need:
+            self._retire(ws)
             ws = torch.empty(need, dtype=torch.float32, device=x_out.device)
             self._ws[key] = ws
         self._call("tpg_mlp_wgrad", "mlp_wgrad", 2 * P * (Cout + Cin) + (0 if mode else 2 * P * Cout), x_out,
@@ -551,6 +563,7 @@ class HipBackend:
         key = ("small_tail", h.device, torch.cuda.current_stream(h.device).cuda_stream)
         ws = self._ws.get(key)
         if ws is None or ws.numel() < need:
+            self._retire(ws)
             ws = torch.empty(need, dtype=torch.float32, device=h.device)
             self._ws[key] = ws
         self._call("tpg_small_tail_bwd", "small_tail_bwd", h.element_size() * (2 * E * H + 2 * P * C2) + P * C2, h,
