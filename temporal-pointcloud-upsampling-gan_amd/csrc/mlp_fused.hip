@@ -160,7 +160,8 @@ __global__ __launch_bounds__(ML_THREADS, 2) void mlp_fwd_kernel(
                 if ((t & 3) == 3) __builtin_amdgcn_sched_barrier(0);
             }
         }
-        // the next tile's rows travel while this tile's epilogue runs
+        // the next tile's rows travel while this tile's epilogue runs (requesting them k-step by k-step inside the
+        // loop, as the data-gradient kernel does, measured 0-7 % SLOWER here: two waves per SIMD already cover it)
         if (tile + gridDim.x < ntiles) load_tile(tile + gridDim.x);
         // ---- epilogue: round, store rows, accumulate the statistics of the rounded values
         if (!have_piv) {
@@ -472,7 +473,8 @@ __global__ __launch_bounds__(ML_THREADS, OCC) void mlp_dgrad_kernel(
     uint4 xraw[STRIPS][KS], graw[STRIPS][KS];
     uint2 araw[STRIPS][KS];
     unsigned xin[STRIPS][4][TI / 2];          // x_in at the accumulator positions (rows 4*lq + r, channels li*TI ..)
-    auto load_tile = [&](long long tile) {
+    // x_in at the accumulator positions of a tile (consumed by the epilogue)
+    auto load_xin = [&](long long tile) {
 #pragma unroll
         for (int st = 0; st < STRIPS; ++st) {
 #pragma unroll
@@ -491,26 +493,45 @@ __global__ __launch_bounds__(ML_THREADS, OCC) void mlp_dgrad_kernel(
                     }
                 }
             }
-            long long row = tile * BM + (wave * STRIPS + st) * 16 + li;
-            row = row < P ? row : P - 1;
-            const __hip_bfloat16 *px = x_out + (size_t)row * COUT + 8 * lq;
-            const long long grow = MODE == MODE_MAX ? (long long)((unsigned)row / (unsigned)K) : row;
-            const __hip_bfloat16 *pg = g_out + (size_t)grow * COUT + 8 * lq;
-#pragma unroll
-            for (int s = 0; s < KS; ++s) {
-                xraw[st][s] = *reinterpret_cast<const uint4 *>(px + 32 * s);
-                graw[st][s] = *reinterpret_cast<const uint4 *>(pg + 32 * s);
-                if (MODE == MODE_MAX)
-                    araw[st][s] = *reinterpret_cast<const uint2 *>(arg + (size_t)grow * COUT + 8 * lq + 32 * s);
-                else
-                    araw[st][s] = make_uint2(0u, 0u);
-            }
         }
     };
+    // the k-step operands of a tile: the lane's 8 output channels 32 s + 8 lq of row li of every strip
+    const __hip_bfloat16 *px[STRIPS], *pg[STRIPS];
+    const uint8_t *pa[STRIPS];
+    auto point_at = [&](long long tile) {
+#pragma unroll
+        for (int st = 0; st < STRIPS; ++st) {
+            long long row = tile * BM + (wave * STRIPS + st) * 16 + li;
+            row = row < P ? row : P - 1;
+            px[st] = x_out + (size_t)row * COUT + 8 * lq;
+            const long long grow = MODE == MODE_MAX ? (long long)((unsigned)row / (unsigned)K) : row;
+            pg[st] = g_out + (size_t)grow * COUT + 8 * lq;
+            pa[st] = MODE == MODE_MAX ? arg + (size_t)grow * COUT + 8 * lq : nullptr;
+        }
+    };
+    auto load_step = [&](int st, int s) {
+        xraw[st][s] = *reinterpret_cast<const uint4 *>(px[st] + 32 * s);
+        graw[st][s] = *reinterpret_cast<const uint4 *>(pg[st] + 32 * s);
+        if (MODE == MODE_MAX) araw[st][s] = *reinterpret_cast<const uint2 *>(pa[st] + 32 * s);
+        else araw[st][s] = make_uint2(0u, 0u);
+    };
     long long tile = blockIdx.x;
-    if (tile < ntiles) load_tile(tile);
+    if (tile < ntiles) {
+        point_at(tile);
+#pragma unroll
+        for (int st = 0; st < STRIPS; ++st)
+#pragma unroll
+            for (int s = 0; s < KS; ++s) load_step(st, s);
+        load_xin(tile);
+    }
     for (; tile < ntiles; tile += gridDim.x) {
         const long long row_base = tile * BM + (long long)wave * STRIPS * 16;
+        // The NEXT tile's k-step operands are requested as soon as this tile's k-step has been turned into its A
+        // fragment (the registers are free from then on): they travel during the rest of the k-loop and the epilogue.
+        // With the whole request after the epilogue, a wave -- the only one on its SIMD for the wide layers -- sat
+        // out the full memory latency once per tile: 65 % of its cycles (SQ_WAIT_ANY), 3.3 of 8 TB/s.
+        const bool has_next = tile + gridDim.x < ntiles;
+        if (has_next) point_at(tile + gridDim.x);
         f32x4 acc[STRIPS][TI];
 #pragma unroll
         for (int st = 0; st < STRIPS; ++st)
@@ -531,6 +552,7 @@ __global__ __launch_bounds__(ML_THREADS, OCC) void mlp_dgrad_kernel(
                              cf, cfm, cv.u);
                 if (row >= P) { cv.u[0] = 0u; cv.u[1] = 0u; cv.u[2] = 0u; cv.u[3] = 0u; }
                 afrag[st] = cv.v;
+                if (has_next) load_step(st, s);
             }
 #pragma unroll
             for (int t = 0; t < TI; ++t) {
@@ -570,8 +592,7 @@ __global__ __launch_bounds__(ML_THREADS, OCC) void mlp_dgrad_kernel(
                     if constexpr (TI == 4) *reinterpret_cast<uint2 *>(pg) = make_uint2(o[0], o[1]);
                 }
             }
-        // the next tile's operands travel while the other waves of the CU compute
-        if (tile + gridDim.x < ntiles) load_tile(tile + gridDim.x);
+        if (has_next) load_xin(tile + gridDim.x);
     }
     // ---- per-wave sums -> per-workgroup partials (fixed order)
 #pragma unroll
