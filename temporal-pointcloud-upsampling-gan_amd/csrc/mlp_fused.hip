@@ -473,8 +473,16 @@ __global__ __launch_bounds__(ML_THREADS, OCC) void mlp_dgrad_kernel(
     uint4 xraw[STRIPS][KS], graw[STRIPS][KS];
     uint2 araw[STRIPS][KS];
     unsigned xin[STRIPS][4][TI / 2];          // x_in at the accumulator positions (rows 4*lq + r, channels li*TI ..)
+    // One wave per SIMD (the wide layers): nothing else covers this wave's waits, and hipcc waits vmcnt(0) at the top
+    // of the tile loop -- for EVERYTHING outstanding.  Whatever is requested or stored at the end of a tile is then
+    // awaited in full at the top of the next: x_in of the next tile goes into a second register set at the START of
+    // the k-loop, and a tile's rows are stored during the NEXT tile's k-loop.
+    constexpr bool DEFER = OCC == 1 && CIN == 128;   // (measured: 128 -> 256 +5 %; with 256 input channels the two extra sets cost more than they hide: -13 %)
+    unsigned xnext[DEFER ? STRIPS : 1][4][TI / 2];
+    unsigned held[DEFER ? STRIPS : 1][4][TI / 2];   // the previous tile's bf16 rows of g_in, not yet stored
+    long long held_base = -1;                  // row_base of the held tile (-1: nothing held)
     // x_in at the accumulator positions of a tile (consumed by the epilogue)
-    auto load_xin = [&](long long tile) {
+    auto load_xin = [&](long long tile, unsigned (&xin)[STRIPS][4][TI / 2]) {
 #pragma unroll
         for (int st = 0; st < STRIPS; ++st) {
 #pragma unroll
@@ -522,7 +530,7 @@ __global__ __launch_bounds__(ML_THREADS, OCC) void mlp_dgrad_kernel(
         for (int st = 0; st < STRIPS; ++st)
 #pragma unroll
             for (int s = 0; s < KS; ++s) load_step(st, s);
-        load_xin(tile);
+        load_xin(tile, xin);
     }
     for (; tile < ntiles; tile += gridDim.x) {
         const long long row_base = tile * BM + (long long)wave * STRIPS * 16;
@@ -532,6 +540,24 @@ __global__ __launch_bounds__(ML_THREADS, OCC) void mlp_dgrad_kernel(
         // out the full memory latency once per tile: 65 % of its cycles (SQ_WAIT_ANY), 3.3 of 8 TB/s.
         const bool has_next = tile + gridDim.x < ntiles;
         if (has_next) point_at(tile + gridDim.x);
+        if constexpr (DEFER) {
+            if (has_next) load_xin(tile + gridDim.x, xnext);
+        }
+        auto store_held = [&]() {
+#pragma unroll
+            for (int st = 0; st < STRIPS; ++st)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const long long row = held_base + st * 16 + 4 * lq + r;
+                    if (row < P) {
+                        __hip_bfloat16 *pgo = g_in + (size_t)row * CIN + li * TI;
+#pragma unroll
+                        for (int v4 = 0; v4 < TI / 8; ++v4)
+                            reinterpret_cast<uint4 *>(pgo)[v4] = make_uint4(held[DEFER ? st : 0][r][4 * v4], held[DEFER ? st : 0][r][4 * v4 + 1],
+                                                                            held[DEFER ? st : 0][r][4 * v4 + 2], held[DEFER ? st : 0][r][4 * v4 + 3]);
+                    }
+                }
+        };
         f32x4 acc[STRIPS][TI];
 #pragma unroll
         for (int st = 0; st < STRIPS; ++st)
@@ -562,6 +588,9 @@ __global__ __launch_bounds__(ML_THREADS, OCC) void mlp_dgrad_kernel(
                     acc[st][t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(afrag[st], b, acc[st][t], 0, 0, 0);
                 if ((t & 3) == 3) __builtin_amdgcn_sched_barrier(0);
             }
+            if constexpr (DEFER) {
+                if (s == 0 && held_base >= 0) store_held();
+            }
         }
         // ---- epilogue: + e^T W, the activation's derivative from x_in, BN_in's sums, the bf16 rows of g_in
 #pragma unroll
@@ -584,15 +613,49 @@ __global__ __launch_bounds__(ML_THREADS, OCC) void mlp_dgrad_kernel(
                     sgx[t] = __builtin_fmaf(g0, x0 - mu[t], sgx[t]);
                     sgx[t + 1] = __builtin_fmaf(g1, x1 - mu[t + 1], sgx[t + 1]);
                 }
-                if (valid) {
-                    __hip_bfloat16 *pg = g_in + (size_t)row * CIN + li * TI;
+                if constexpr (DEFER) {
+#pragma unroll
+                    for (int w = 0; w < TI / 2; ++w) held[st][r][w] = o[w];
+                } else if (valid) {
+                    __hip_bfloat16 *pgo = g_in + (size_t)row * CIN + li * TI;
 #pragma unroll
                     for (int v4 = 0; v4 < TI / 8; ++v4)
-                        reinterpret_cast<uint4 *>(pg)[v4] = make_uint4(o[4 * v4], o[4 * v4 + 1], o[4 * v4 + 2], o[4 * v4 + 3]);
-                    if constexpr (TI == 4) *reinterpret_cast<uint2 *>(pg) = make_uint2(o[0], o[1]);
+                        reinterpret_cast<uint4 *>(pgo)[v4] = make_uint4(o[4 * v4], o[4 * v4 + 1], o[4 * v4 + 2], o[4 * v4 + 3]);
+                    if constexpr (TI == 4) *reinterpret_cast<uint2 *>(pgo) = make_uint2(o[0], o[1]);
                 }
             }
-        if (has_next) load_xin(tile + gridDim.x);
+        if constexpr (DEFER) {
+            held_base = row_base;
+            if (has_next) {
+#pragma unroll
+                for (int st = 0; st < STRIPS; ++st)
+#pragma unroll
+                    for (int r = 0; r < 4; ++r)
+#pragma unroll
+                        for (int w = 0; w < TI / 2; ++w) xin[st][r][w] = xnext[st][r][w];
+            }
+        } else {
+            if (has_next) load_xin(tile + gridDim.x, xin);
+        }
+    }
+    if constexpr (DEFER) {
+        if (held_base >= 0) {
+            auto store_last = [&]() {
+#pragma unroll
+                for (int st = 0; st < STRIPS; ++st)
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) {
+                        const long long row = held_base + st * 16 + 4 * lq + r;
+                        if (row < P) {
+                            __hip_bfloat16 *pgo = g_in + (size_t)row * CIN + li * TI;
+#pragma unroll
+                            for (int v4 = 0; v4 < TI / 8; ++v4)
+                                reinterpret_cast<uint4 *>(pgo)[v4] = make_uint4(held[st][r][4 * v4], held[st][r][4 * v4 + 1], held[st][r][4 * v4 + 2], held[st][r][4 * v4 + 3]);
+                        }
+                    }
+            };
+            store_last();
+        }
     }
     // ---- per-wave sums -> per-workgroup partials (fixed order)
 #pragma unroll
