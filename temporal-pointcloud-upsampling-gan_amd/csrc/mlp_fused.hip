@@ -538,11 +538,12 @@ __global__ __launch_bounds__(ML_THREADS, OCC) void mlp_dgrad_kernel(
         // fragment (the registers are free from then on): they travel during the rest of the k-loop and the epilogue.
         // With the whole request after the epilogue, a wave -- the only one on its SIMD for the wide layers -- sat
         // out the full memory latency once per tile: 65 % of its cycles (SQ_WAIT_ANY), 3.3 of 8 TB/s.
+        // (the last tile re-requests itself: UNCONDITIONAL loads keep the loop body straight-line, so that hipcc can
+        // count what is outstanding -- behind an `if (has_next)` per request it fell back to vmcnt(0) at the loop top)
         const bool has_next = tile + gridDim.x < ntiles;
-        if (has_next) point_at(tile + gridDim.x);
-        if constexpr (DEFER) {
-            if (has_next) load_xin(tile + gridDim.x, xnext);
-        }
+        const long long tnext = has_next ? tile + gridDim.x : tile;
+        point_at(tnext);
+        if constexpr (DEFER) load_xin(tnext, xnext);
         auto store_held = [&]() {
 #pragma unroll
             for (int st = 0; st < STRIPS; ++st)
@@ -578,7 +579,7 @@ __global__ __launch_bounds__(ML_THREADS, OCC) void mlp_dgrad_kernel(
                              cf, cfm, cv.u);
                 if (row >= P) { cv.u[0] = 0u; cv.u[1] = 0u; cv.u[2] = 0u; cv.u[3] = 0u; }
                 afrag[st] = cv.v;
-                if (has_next) load_step(st, s);
+                load_step(st, s);
             }
 #pragma unroll
             for (int t = 0; t < TI; ++t) {
@@ -626,16 +627,14 @@ __global__ __launch_bounds__(ML_THREADS, OCC) void mlp_dgrad_kernel(
             }
         if constexpr (DEFER) {
             held_base = row_base;
-            if (has_next) {
 #pragma unroll
-                for (int st = 0; st < STRIPS; ++st)
+            for (int st = 0; st < STRIPS; ++st)
 #pragma unroll
-                    for (int r = 0; r < 4; ++r)
+                for (int r = 0; r < 4; ++r)
 #pragma unroll
-                        for (int w = 0; w < TI / 2; ++w) xin[st][r][w] = xnext[st][r][w];
-            }
+                    for (int w = 0; w < TI / 2; ++w) xin[st][r][w] = xnext[st][r][w];
         } else {
-            if (has_next) load_xin(tile + gridDim.x, xin);
+            load_xin(tnext, xin);
         }
     }
     if constexpr (DEFER) {
