@@ -58,6 +58,10 @@ def _feature_cloud(rng, B, P, D, kind):
         x = np.tanh(z @ rng.standard_normal((3, D)).astype(np.float32)) + 0.05 * rng.standard_normal((B, P, D)).astype(np.float32)
     else:
         x = rng.standard_normal((B, P, D)).astype(np.float32)
+    if kind == "lattice":
+        # small integers: distances are small integers too -- exact ties everywhere, in particular AT the K-th
+        # distance, where only the (dist, idx) order decides and the filter's margin test must give up
+        x = rng.integers(0, 3, (B, P, D)).astype(np.float32) * 0.5
     if kind == "offset":
         x += 300.0
     if kind == "dups":
@@ -68,7 +72,7 @@ def _feature_cloud(rng, B, P, D, kind):
 @pytest.mark.parametrize("B,P1,P2,D,K,kind", [
     (2, 4096, 4096, 32, 20, "manifold"), (1, 4096, 4096, 64, 12, "manifold"), (1, 2048, 2048, 32, 10, "normal"),
     (1, 3000, 5000, 64, 8, "normal"), (1, 4096, 4096, 32, 20, "offset"), (1, 2500, 2500, 32, 20, "dups"),
-    (1, 700, 16384, 64, 24, "manifold")])
+    (1, 700, 16384, 64, 24, "manifold"), (1, 2048, 2048, 32, 20, "lattice"), (1, 600, 4096, 64, 12, "lattice")])
 def test_knn_matrix_core_filter_bit_exact(hip, B, P1, P2, D, K, kind):
     """tpg_knn_f32 on clouds of >= 2048 points in 32 / 64 dims runs the Gram filter on the f32 matrix cores and
     re-ranks the survivors exactly (csrc/knn_mfma.hpp): indices and distances equal the oracle's bit for bit,
