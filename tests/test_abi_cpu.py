@@ -75,3 +75,26 @@ def test_validation_errors_match_upstream_style(oracle_cpu):
                                torch.zeros(1, 4, 2, dtype=torch.int32))
     with pytest.raises(RuntimeError, match="float tensor"):
         ops.furthest_point_sample(torch.zeros(1, 8, 3, dtype=torch.float64), 4)
+
+
+def test_new_entries_reject_bad_arguments_before_any_launch(hip_lib):
+    """Argument checks of the round-2 entries return their status codes without touching a device (no GPU here):
+    unsupported shapes are TPG_ERR_UNSUPPORTED (-3), malformed calls TPG_ERR_ARG (-1), empty work TPG_OK."""
+    import ctypes as C
+    buf = (C.c_float * 64)()
+    p = C.cast(buf, C.c_void_p)
+    # feature-space kNN filter: D in {32, 64}, 2 <= K <= 24
+    assert hip_lib.tpg_knn_mfma_f32(p, p, None, None, 1, 8, 8, 48, 4, p, p, 1, None) == -3
+    assert hip_lib.tpg_knn_mfma_f32(p, p, None, None, 1, 8, 8, 32, 25, p, p, 1, None) == -3
+    assert hip_lib.tpg_knn_mfma_f32(p, p, None, None, 1, 8, 8, 32, 1, p, p, 1, None) == -1
+    assert hip_lib.tpg_knn_mfma_f32(p, p, None, None, 0, 8, 8, 32, 4, p, p, 1, None) == 0
+    # grid searches: K <= 64, workspace required
+    assert hip_lib.tpg_knn_grid_f32(p, p, None, None, 1, 8, 8, 65, p, p, p, None) == -1
+    assert hip_lib.tpg_knn_grid_f32(p, p, None, None, 1, 8, 8, 4, p, p, None, None) == -1
+    assert hip_lib.tpg_knn_grid_f32(p, p, None, None, 1, 0, 8, 4, p, p, p, None) == 0
+    assert hip_lib.tpg_frnn_grid_f32(p, p, None, None, 1, 8, 8, 4, 0.0, p, p, p, None) == -1
+    # the 16 -> 16 -> 32 tails: other channel counts are not built
+    assert hip_lib.tpg_small_tail_fwd(p, 0, p, p, 0.2, 0.2, 16, 4, 32, 16, 32, p, p, None) == -3
+    assert hip_lib.tpg_small_tail_fwd(p, 0, p, p, 0.2, 0.2, 16, 0, 16, 16, 32, p, p, None) == -1
+    assert hip_lib.tpg_small_tail_fwd(p, 0, p, p, 0.2, 0.2, 0, 4, 16, 16, 32, p, p, None) == 0
+    assert hip_lib.tpg_small_tail_workspace_bytes(12288, 20) > 0 and hip_lib.tpg_frnn_grid_workspace_bytes(0, 8) == 0
