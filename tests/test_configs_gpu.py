@@ -88,3 +88,28 @@ def test_cfg5_discriminators_forward_backward_at_16384_points():
             rel = float((a - b).norm() / a.norm().clamp_min(1e-12))
             print("   gradient relative L2 difference", rel)
             assert rel <= 5e-2, rel
+
+
+def test_rollout_on_a_large_scene_matches_the_reference_order():
+    """SURVEY section 8 row f3 at the size it is about: `SRNet.forward_with_context` on ONE cloud of 20000 points
+    (upsampling_network.py:159-174).  The feature-space searches run the matrix-core filter, the 3-D search the
+    grid; the reference order of operations (grouping_operation route) must see the same neighbours, so the two
+    forms agree to summation order, frame after frame (the running mask average included)."""
+    from tpgan_amd.set_abstraction import reference_order
+    from tpgan_amd.srnet import SRNet
+    from tpgan_amd.synthetic import fluid_clip, force_all_keep
+    dev = torch.device("cuda", 0)
+    torch.manual_seed(4)
+    net = force_all_keep(SRNet(3, 128, upsample_ratio=8)).to(dev).eval()
+    low, _ = fluid_clip(1, 20000, 1, 2, seed=8, device=dev)
+    outs = []
+    for ref in (False, True):
+        hist, frames = [], []
+        with torch.no_grad(), reference_order(ref):
+            for x in low:
+                out, hist = net.forward_with_context(x, x, hist)
+                frames.append(out)
+        outs.append(frames)
+    for a, b in zip(*outs):
+        assert a.shape == (1, 8 * 20000, 3) and torch.isfinite(a).all()
+        assert float((a - b).abs().max()) <= 1e-4 * max(1.0, float(b.abs().max())), float((a - b).abs().max())
