@@ -73,7 +73,9 @@ __global__ __launch_bounds__(ML_THREADS, 2) void mlp_fwd_kernel(
     extern __shared__ __attribute__((aligned(16))) unsigned char ml_smem[];
     unsigned short *wl = reinterpret_cast<unsigned short *>(ml_smem);                  // [COUT][WROW]
     float *cst = reinterpret_cast<float *>(ml_smem + (size_t)COUT * WROW * 2);         // [2][CIN]
-    float *red = cst + 2 * CIN;                                                        // [ML_WAVES][3][COUT]
+    // [ML_WAVES][3][COUT], used after the tile loop only: it lies ON the weight (12 KB of its own put the 128 -> 256
+    // layer at 81 KB, 2 KB too many for two workgroups per CU -- the launch ran at one wave per SIMD in 1.5 rounds)
+    float *red = reinterpret_cast<float *>(ml_smem);
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int li = lane & 15, lq = lane >> 4;
     const int seg = blockIdx.y;
@@ -213,6 +215,7 @@ __global__ __launch_bounds__(ML_THREADS, 2) void mlp_fwd_kernel(
         s2[t] += __shfl_xor(s2[t], 16, 64);
         s2[t] += __shfl_xor(s2[t], 32, 64);
     }
+    __syncthreads();                          // every wave is done with the weight: `red` takes its place
     if (lq == 0) {
 #pragma unroll
         for (int t = 0; t < T; ++t) {
@@ -1020,13 +1023,16 @@ template <int CIN, int COUT> constexpr int fwd_strips() {
     return (COUT <= 128 && CIN <= 128) ? 2 : 1;
 }
 template <int CIN, int COUT> constexpr size_t fwd_smem() {
-    return (size_t)COUT * (CIN + ML_WPAD) * 2 + sizeof(float) * (2 * CIN + ML_WAVES * 3 * COUT);
+    constexpr size_t w = (size_t)COUT * (CIN + ML_WPAD) * 2, red = sizeof(float) * ML_WAVES * 3 * COUT;
+    return (w > red ? w : red) + sizeof(float) * 2 * CIN;      // (the reduction scratch aliases the weight)
 }
 
 int fwd_blocks(long long P, int bm, int nseg) {
     const long long tiles = (P + bm - 1) / bm;
-    long long cap = ML_MAX_BLOCKS / (nseg > 4 ? 4 : nseg);          // segments share the chip
-    if (cap < 64) cap = 64;
+    // segments share the chip: ~512 workgroups in all = one round at two per CU, two at one per CU (six segments at
+    // 128 each were 768: one and a half rounds, the second half empty)
+    long long cap = ML_MAX_BLOCKS / nseg;
+    if (cap < 16) cap = 16;
     return (int)(tiles < cap ? tiles : cap);
 }
 
@@ -1101,6 +1107,13 @@ int wgrad_blocks(long long P, int nseg, int Cin, int Cout) {
     long long g = P * (Cin + Cout) / (8LL * Cin * Cout);         // slab traffic <= 1/2 of the rows'
     const long long lo = 256 / d, hi = 768 / d;                  // ... but never fewer workgroups than CUs
     g = g < lo ? lo : (g > hi ? hi : g);
+    // whole rounds: the launch's g * nseg workgroups against what the chip holds at once (one workgroup per CU for
+    // the wide layers, two otherwise) -- 576 workgroups on 256 slots were three rounds for two and a quarter of work
+    const long long slots = ((long long)Cout * Cin / ML_THREADS >= 128) ? 256 : 512;
+    long long k = g * nseg / slots;                              // (down: fewer slabs to write and re-read)
+    if (k < 1) k = 1;
+    g = k * slots / nseg;
+    if (g < 1) g = 1;
     return (int)(g < tiles ? g : tiles);
 }
 
