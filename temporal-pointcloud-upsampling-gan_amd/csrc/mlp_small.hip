@@ -255,7 +255,8 @@ __global__ __launch_bounds__(1024) void small_tail_reduce_kernel(const float *__
 int small_bwd_blocks(long long P) {
     const long long tiles = (P + 15) / 16;
     long long blocks = (tiles + SB_WAVES - 1) / SB_WAVES;
-    const long long cap = 256;                               // 1024 persistent waves (one per SIMD): 3 MB of slabs
+    const long long cap = 1024;                              // 4096 persistent waves (four per SIMD: 86 registers, 20 KB of LDS
+                                                             // per workgroup; one per SIMD left every load latency bare): 12 MB of slabs
     if (blocks > cap) blocks = cap;
     return (int)(blocks < 1 ? 1 : blocks);
 }
