@@ -511,7 +511,10 @@ int bwd_go(const void *gout, const int32_t *idx, const int32_t *offs, const int3
     TI *gu = static_cast<TI *>(gU), *gq = static_cast<TI *>(gQE);
     const unsigned cpr = (unsigned)(C / NE);
 #ifndef TPG_RC_BWD_THREAD_PER_ROW
-    const bool by_wave = cpr <= 32 && (64u % cpr) == 0;     // a wave per row needs >= 2 lane groups
+    // a wave per row needs >= 2 lane groups; for the generator's 16-channel EDGE rows (two chunks per row, ~k entries
+    // per list) a wave is 32 groups for ~20 entries of 32 bytes: a thread per chunk walks them faster (cfg5's 163840 rows:
+    // K = 10 217 -> 139 us, K = 20 277 -> 248 us, inverse index included)
+    const bool by_wave = cpr <= 32 && (64u % cpr) == 0 && !(mode == MODE_EDGE && cpr <= 2);
 #else
     const bool by_wave = false;
 #endif
