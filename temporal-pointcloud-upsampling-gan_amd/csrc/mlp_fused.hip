@@ -253,57 +253,53 @@ __global__ __launch_bounds__(ML_THREADS, 2) void mlp_fwd_kernel(
 // partials, fp64, fixed order -> bitwise reproducible.  ss_next (nseg, 2, C), optional: scale | shift
 // of THIS BatchNorm (gamma * rstd | beta - mean * gamma * rstd) for the consumer's prologue.
 constexpr int MF_CH = 4;
-constexpr int MF_LANES = ML_THREADS / MF_CH;
+__device__ __forceinline__ double mf_wave_sum(double v) {
+#pragma unroll
+    for (int m = 32; m > 0; m >>= 1) v += __shfl_xor(v, m, 64);      // fixed butterfly: every lane ends with the same bits
+    return v;
+}
+
+// One WAVE per channel (MF_CH = 4 channels per workgroup), its lanes over the G partials: the sums are wave
+// butterflies in fp64, no LDS and no barrier (an LDS tree per pass and segment was ~20 barriers a segment: 24 us per
+// launch at cfg4's 16 segments, 42 launches per step on the discriminators' chains).
 __global__ __launch_bounds__(ML_THREADS) void mlp_stats_finalize_kernel(
     const float *__restrict__ part, int G, int C, int nseg, float eps, float momentum,
     float *__restrict__ running_mean, float *__restrict__ running_var, long long *__restrict__ num_batches_tracked,
     const float *__restrict__ mean_shift, const float *__restrict__ gamma, const float *__restrict__ beta,
     float *__restrict__ mean, float *__restrict__ rstd, float *__restrict__ ci_out) {
-    __shared__ double red[3][MF_LANES][MF_CH];
-    const int cl = threadIdx.x % MF_CH, gl = threadIdx.x / MF_CH;
-    const int c = blockIdx.x * MF_CH + cl;
+    const int lane = threadIdx.x & 63;
+    const int c = blockIdx.x * MF_CH + (threadIdx.x >> 6);
     if (num_batches_tracked && blockIdx.x == 0 && threadIdx.x == 0) *num_batches_tracked += nseg;
+    if (c >= C) return;                              // whole wave
+    float rmean = running_mean ? running_mean[c] : 0.0f, rvar = running_mean ? running_var[c] : 0.0f;
     for (int seg = 0; seg < nseg; ++seg) {          // in call order: the running statistics chain
         const float *ps = part + (size_t)seg * G * 3 * C;
         // pass 1: N and the weighted mean
         double n = 0.0, sm = 0.0;
-        if (c < C)
-            for (int g = gl; g < G; g += MF_LANES) {
-                const double ng = ps[((size_t)g * 3 + 2) * C + c];
-                n += ng;
-                sm += ng * (double)ps[((size_t)g * 3 + 0) * C + c];
-            }
-        red[0][gl][cl] = n;
-        red[1][gl][cl] = sm;
-        __syncthreads();
-        for (int sft = MF_LANES / 2; sft > 0; sft >>= 1) {
-            if (gl < sft) {
-                red[0][gl][cl] += red[0][gl + sft][cl];
-                red[1][gl][cl] += red[1][gl + sft][cl];
-            }
-            __syncthreads();
+        for (int g = lane; g < G; g += 64) {
+            const double ng = ps[((size_t)g * 3 + 2) * C + c];
+            n += ng;
+            sm += ng * (double)ps[((size_t)g * 3 + 0) * C + c];
         }
-        const double N = red[0][0][cl];
-        const double m = N > 0.0 ? red[1][0][cl] / N : 0.0;
-        __syncthreads();
+        const double N = mf_wave_sum(n);
+        const double m = N > 0.0 ? mf_wave_sum(sm) / N : 0.0;
         // pass 2: M2 = sum M2_g + n_g (mean_g - mean)^2
         double q = 0.0;
-        if (c < C)
-            for (int g = gl; g < G; g += MF_LANES) {
-                const double ng = ps[((size_t)g * 3 + 2) * C + c];
-                const double d = (double)ps[((size_t)g * 3 + 0) * C + c] - m;
-                q += (double)ps[((size_t)g * 3 + 1) * C + c] + ng * d * d;
-            }
-        red[2][gl][cl] = q;
-        __syncthreads();
-        for (int sft = MF_LANES / 2; sft > 0; sft >>= 1) {
-            if (gl < sft) red[2][gl][cl] += red[2][gl + sft][cl];
-            __syncthreads();
+        for (int g = lane; g < G; g += 64) {
+            const double ng = ps[((size_t)g * 3 + 2) * C + c];
+            const double d = (double)ps[((size_t)g * 3 + 0) * C + c] - m;
+            q += (double)ps[((size_t)g * 3 + 1) * C + c] + ng * d * d;
         }
-        if (gl == 0 && c < C) {
-            double var = N > 0.0 ? red[2][0][cl] / N : 0.0;          // biased
-            var = var < 0.0 ? 0.0 : var;
-            const float mu = (float)m, rs = (float)(1.0 / sqrt(var + (double)eps));
+        double var = N > 0.0 ? mf_wave_sum(q) / N : 0.0;          // biased
+        var = var < 0.0 ? 0.0 : var;
+        const float mu = (float)m, rs = (float)(1.0 / sqrt(var + (double)eps));
+        if (running_mean) {
+            const double unbiased = N > 1.0 ? var * N / (N - 1.0) : var;
+            const double shift = mean_shift ? (double)mean_shift[c] : 0.0;
+            rmean = (float)((1.0 - momentum) * rmean + momentum * (m + shift));
+            rvar = (float)((1.0 - momentum) * rvar + momentum * unbiased);
+        }
+        if (lane == 0) {
             if (mean) mean[(size_t)seg * C + c] = mu;
             if (rstd) rstd[(size_t)seg * C + c] = rs;
             if (ci_out) {
@@ -311,15 +307,9 @@ __global__ __launch_bounds__(ML_THREADS) void mlp_stats_finalize_kernel(
                 float *o = ci_out + (size_t)seg * 4 * C + c;
                 o[0] = a; o[C] = (beta ? beta[c] : 0.0f) - mu * a; o[2 * C] = mu; o[3 * C] = rs;
             }
-            if (running_mean) {
-                const double unbiased = N > 1.0 ? var * N / (N - 1.0) : var;
-                const double shift = mean_shift ? (double)mean_shift[c] : 0.0;
-                running_mean[c] = (float)((1.0 - momentum) * running_mean[c] + momentum * (m + shift));
-                running_var[c] = (float)((1.0 - momentum) * running_var[c] + momentum * unbiased);
-            }
         }
-        __syncthreads();
     }
+    if (running_mean && lane == 0) { running_mean[c] = rmean; running_var[c] = rvar; }
 }
 
 // ------------------------------------------------------------------------------------ backward
@@ -694,32 +684,22 @@ __global__ __launch_bounds__(ML_THREADS) void mlp_bwd_finalize_kernel(const floa
                                                                       float *__restrict__ dbeta,
                                                                       const float *__restrict__ ci,
                                                                       float *__restrict__ cb) {
-    __shared__ double red[2][MF_LANES][MF_CH];
-    const int cl = threadIdx.x % MF_CH, gl = threadIdx.x / MF_CH;
-    const int c = blockIdx.x * MF_CH + cl;
+    // one wave per channel, lanes over the partials (see mlp_stats_finalize_kernel)
+    const int lane = threadIdx.x & 63;
+    const int c = blockIdx.x * MF_CH + (threadIdx.x >> 6);
+    if (c >= C) return;
     double ts = 0.0, tsx = 0.0;
     for (int seg = 0; seg < nseg; ++seg) {
         const float *ps = part + (size_t)seg * G * 2 * C;
         double a0 = 0.0, a1 = 0.0;
-        if (c < C)
-            for (int g = gl; g < G; g += MF_LANES) {
-                a0 += ps[((size_t)g * 2 + 0) * C + c];
-                a1 += ps[((size_t)g * 2 + 1) * C + c];
-            }
-        red[0][gl][cl] = a0;
-        red[1][gl][cl] = a1;
-        __syncthreads();
-        for (int sft = MF_LANES / 2; sft > 0; sft >>= 1) {
-            if (gl < sft) {
-                red[0][gl][cl] += red[0][gl + sft][cl];
-                red[1][gl][cl] += red[1][gl + sft][cl];
-            }
-            __syncthreads();
+        for (int g = lane; g < G; g += 64) {
+            a0 += ps[((size_t)g * 2 + 0) * C + c];
+            a1 += ps[((size_t)g * 2 + 1) * C + c];
         }
-        if (gl == 0 && c < C) {
-            const double s = red[0][0][cl], sx = red[1][0][cl] * (double)rstd[(size_t)seg * rstd_stride + c];
-            ts += s;
-            tsx += sx;
+        const double s = mf_wave_sum(a0), sx = mf_wave_sum(a1) * (double)rstd[(size_t)seg * rstd_stride + c];
+        ts += s;
+        tsx += sx;
+        if (lane == 0) {
             const float c1 = (float)(s / (double)P), c2 = (float)(sx / (double)P);
             if (c12) {
                 c12[((size_t)seg * 2 + 0) * C + c] = c1;
@@ -734,9 +714,8 @@ __global__ __launch_bounds__(ML_THREADS) void mlp_bwd_finalize_kernel(const floa
                 o[0] = a; o[C] = f * mu; o[2 * C] = -a * c1; o[3 * C] = f;
             }
         }
-        __syncthreads();
     }
-    if (gl == 0 && c < C) {
+    if (lane == 0) {
         if (dbeta) dbeta[c] = (float)ts;
         if (dgamma) dgamma[c] = (float)tsx;
     }
