@@ -203,14 +203,16 @@ __device__ __forceinline__ void block_column_reduce(float (&acc)[NQ][NE], int cp
     }
 }
 
-// Sum the per-workgroup partials of two quantities: a workgroup owns FIN_CH channels, each
-// summed by 256/FIN_CH lanes over the partial rows (a handful of independent loads per lane,
-// not a 64-deep dependent chain), fp64, one LDS step.  True in the lane that owns channel c.
+// Sum the per-workgroup partials of two quantities: a workgroup is ONE wave that owns FIN_CH channels, each
+// summed by 64/FIN_CH lanes over the partial rows (a handful of independent loads per lane, not a 64-deep
+// dependent chain), then an fp64 butterfly over those lanes -- no LDS and no barrier (the LDS tree this replaces
+// was seven barriers per segment, and the segments of a launch run back to back in one workgroup).
+// True in the lane that owns channel c.
 constexpr int FIN_CH = 4;
-constexpr int FIN_LANES = BN_THREADS / FIN_CH;
+constexpr int FIN_THREADS = 64;
+constexpr int FIN_LANES = FIN_THREADS / FIN_CH;
 __device__ __forceinline__ bool finalize_sums(const float *__restrict__ part, int G, int C, int &c, double &s0,
                                               double &s1) {
-    __shared__ double red[2][FIN_LANES][FIN_CH];
     const int cl = threadIdx.x % FIN_CH, gl = threadIdx.x / FIN_CH;
     c = blockIdx.x * FIN_CH + cl;
     double a0 = 0.0, a1 = 0.0;
@@ -219,21 +221,14 @@ __device__ __forceinline__ bool finalize_sums(const float *__restrict__ part, in
             a0 += part[((size_t)g * 2 + 0) * C + c];
             a1 += part[((size_t)g * 2 + 1) * C + c];
         }
-    red[0][gl][cl] = a0;
-    red[1][gl][cl] = a1;
-    __syncthreads();
-    // tree over the FIN_LANES partial sums of each channel
-    for (int sft = FIN_LANES / 2; sft > 0; sft >>= 1) {
-        if (gl < sft) {
-            red[0][gl][cl] += red[0][gl + sft][cl];
-            red[1][gl][cl] += red[1][gl + sft][cl];
-        }
-        __syncthreads();
+#pragma unroll
+    for (int m = FIN_CH; m < FIN_THREADS; m <<= 1) {      // fixed butterfly over the lanes of one channel
+        a0 += __shfl_xor(a0, m, 64);
+        a1 += __shfl_xor(a1, m, 64);
     }
-    if (gl != 0 || c >= C) return false;
-    s0 = red[0][0][cl];
-    s1 = red[1][0][cl];
-    return true;
+    s0 = a0;
+    s1 = a1;
+    return gl == 0 && c < C;
 }
 
 // ------------------------------------------------------------------ forward statistics
@@ -279,7 +274,7 @@ __global__ __launch_bounds__(BN_THREADS) void rowbn_stats_kernel(const T *__rest
 // partials -> mean, rstd (+ running statistics and the batch counter, as nn.BatchNorm does);
 // grid = ceil(C/FIN_CH)
 template <typename T>
-__global__ __launch_bounds__(BN_THREADS) void rowbn_stats_finalize_kernel(
+__global__ __launch_bounds__(FIN_THREADS) void rowbn_stats_finalize_kernel(
     const T *__restrict__ x, const float *__restrict__ ws, int G, long long P, int C, float eps,
     float momentum, float *__restrict__ running_mean, float *__restrict__ running_var,
     long long *__restrict__ num_batches_tracked, const float *__restrict__ mean_shift, float *__restrict__ mean,
@@ -303,7 +298,6 @@ __global__ __launch_bounds__(BN_THREADS) void rowbn_stats_finalize_kernel(
                 running_var[c] = (float)((1.0 - momentum) * running_var[c] + momentum * unbiased);
             }
         }
-        __syncthreads();                       // finalize_sums' LDS is reused by the next segment
     }
 }
 
@@ -483,7 +477,7 @@ __global__ __launch_bounds__(BN_THREADS) void rowbn_max_combine_kernel(
 // ------------------------------------------------------------------ backward reductions
 // partials (sum g, sum g*xhat) -> dgamma, dbeta (fp32) and the two per-channel constants of dx
 // (c12 = {sum g / P, sum g*xhat / P}, zero for eval-mode statistics); grid = ceil(C/FIN_CH)
-__global__ __launch_bounds__(BN_THREADS) void rowbn_bwd_finalize_kernel(const float *__restrict__ ws, int G,
+__global__ __launch_bounds__(FIN_THREADS) void rowbn_bwd_finalize_kernel(const float *__restrict__ ws, int G,
                                                                         long long P, int C, int training,
                                                                         float *__restrict__ dgamma,
                                                                         float *__restrict__ dbeta,
@@ -501,7 +495,6 @@ __global__ __launch_bounds__(BN_THREADS) void rowbn_bwd_finalize_kernel(const fl
             cs[c] = training ? (float)(s / (double)P) : 0.0f;       // eval-mode BN: no batch terms
             cs[C + c] = training ? (float)(sx / (double)P) : 0.0f;
         }
-        __syncthreads();
     }
     if (!mine) return;
     if (dbeta) dbeta[c] = (float)ts;
@@ -823,12 +816,12 @@ extern "C" int tpg_rowbn_fwd(const void *x, int dtype_in, long long P, int K, in
         if (dtype_in == TPG_DTYPE_BF16) {
             const __hip_bfloat16 *xx = static_cast<const __hip_bfloat16 *>(x);
             hipLaunchKernelGGL(rowbn_stats_kernel<__hip_bfloat16>, dim3(G, nseg), dim3(BN_THREADS), 0, st, xx, P, C, wsf);
-            hipLaunchKernelGGL(rowbn_stats_finalize_kernel<__hip_bfloat16>, fg, dim3(BN_THREADS), 0, st, xx, wsf, G, P,
+            hipLaunchKernelGGL(rowbn_stats_finalize_kernel<__hip_bfloat16>, fg, dim3(FIN_THREADS), 0, st, xx, wsf, G, P,
                                C, eps, momentum, running_mean, running_var, num_batches_tracked, mean_shift, mean, rstd, nseg);
         } else {
             const float *xx = static_cast<const float *>(x);
             hipLaunchKernelGGL(rowbn_stats_kernel<float>, dim3(G, nseg), dim3(BN_THREADS), 0, st, xx, P, C, wsf);
-            hipLaunchKernelGGL(rowbn_stats_finalize_kernel<float>, fg, dim3(BN_THREADS), 0, st, xx, wsf, G, P, C, eps,
+            hipLaunchKernelGGL(rowbn_stats_finalize_kernel<float>, fg, dim3(FIN_THREADS), 0, st, xx, wsf, G, P, C, eps,
                                momentum, running_mean, running_var, num_batches_tracked, mean_shift, mean, rstd, nseg);
         }
     }  // eval mode: the caller has filled mean / rstd from the running statistics
@@ -933,7 +926,7 @@ extern "C" int tpg_rowbn_bwd(const void *gy, int dtype_g, const void *x, int dty
             hipLaunchKernelGGL((rowbn_bwd_reduce_kernel<TI, TG>), dim3(G, nseg), dim3(BN_THREADS), 0, st, gg, xx, P, C, \
                                mean, rstd, gamma, beta, slope, wsf);                                        \
         if (need_reduce)                                                                                    \
-            hipLaunchKernelGGL(rowbn_bwd_finalize_kernel, dim3((C + FIN_CH - 1) / FIN_CH), dim3(BN_THREADS), 0, st, \
+            hipLaunchKernelGGL(rowbn_bwd_finalize_kernel, dim3((C + FIN_CH - 1) / FIN_CH), dim3(FIN_THREADS), 0, st, \
                                wsf, G, P, C, training, dgamma, dbeta, c12, nseg);                           \
         if (!do_apply) {                                                                                    \
         } else if (K > 0) {                                                                                 \
