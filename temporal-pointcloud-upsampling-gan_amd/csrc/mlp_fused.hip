@@ -259,9 +259,31 @@ __device__ __forceinline__ double mf_wave_sum(double v) {
     return v;
 }
 
-// One WAVE per channel (MF_CH = 4 channels per workgroup), its lanes over the G partials: the sums are wave
-// butterflies in fp64, no LDS and no barrier (an LDS tree per pass and segment was ~20 barriers a segment: 24 us per
-// launch at cfg4's 16 segments, 42 launches per step on the discriminators' chains).
+// The segments of a launch are independent except for the running statistics, and a segment has few partials
+// (segments x partials <= the resident workgroups of the producing launch), so a wave's lanes are split into GROUPS,
+// one per segment: SP = segments per sweep (a power of two), L = 64 / SP lanes per segment.
+struct MfSplit { int SP, L; };
+__device__ __forceinline__ MfSplit mf_split(int nseg) {
+    int sp = 1;
+    while (sp < nseg && sp < 64) sp <<= 1;
+    return {sp, 64 / sp};
+}
+__device__ __forceinline__ double mf_group_sum(double v, int L) {
+    for (int m = L >> 1; m > 0; m >>= 1) v += __shfl_xor(v, m, 64);      // fixed butterfly inside the group
+    return v;
+}
+__device__ __forceinline__ double mf_readlane(double v, int l) {          // l wave-uniform
+    const long long b = __double_as_longlong(v);
+    const int lo = __builtin_amdgcn_readlane((int)(unsigned)(b & 0xffffffffll), l);
+    const int hi = __builtin_amdgcn_readlane((int)(b >> 32), l);
+    return __longlong_as_double(((long long)hi << 32) | (long long)(unsigned)lo);
+}
+constexpr int MF_R = 8;      // partials a lane keeps in registers between the two passes
+
+// One WAVE per channel (MF_CH = 4 channels per workgroup), no LDS and no barrier.  All segments of a sweep are
+// reduced side by side (a lane group each): the launch waits for memory twice per sweep, not twice per segment
+// (segment after segment it was 2 x 16 dependent round trips at cfg4 = 20 us per launch, 42 launches per step).
+// Only the running statistics walk the segments in call order, from registers.
 __global__ __launch_bounds__(ML_THREADS) void mlp_stats_finalize_kernel(
     const float *__restrict__ part, int G, int C, int nseg, float eps, float momentum,
     float *__restrict__ running_mean, float *__restrict__ running_var, long long *__restrict__ num_batches_tracked,
@@ -271,41 +293,69 @@ __global__ __launch_bounds__(ML_THREADS) void mlp_stats_finalize_kernel(
     const int c = blockIdx.x * MF_CH + (threadIdx.x >> 6);
     if (num_batches_tracked && blockIdx.x == 0 && threadIdx.x == 0) *num_batches_tracked += nseg;
     if (c >= C) return;                              // whole wave
+    const MfSplit sp = mf_split(nseg);
+    const int grp = lane / sp.L, sub = lane - grp * sp.L;
+    const bool fits = G <= sp.L * MF_R;              // the partials of a segment fit its lanes' registers
     float rmean = running_mean ? running_mean[c] : 0.0f, rvar = running_mean ? running_var[c] : 0.0f;
-    for (int seg = 0; seg < nseg; ++seg) {          // in call order: the running statistics chain
-        const float *ps = part + (size_t)seg * G * 3 * C;
+    const double shift = mean_shift ? (double)mean_shift[c] : 0.0;
+    for (int seg0 = 0; seg0 < nseg; seg0 += sp.SP) {
+        const int seg = seg0 + grp;
+        const bool live = seg < nseg;
+        const float *ps = part + (size_t)(live ? seg : nseg - 1) * G * 3 * C + c;
+        float pn[MF_R], pm[MF_R], pq[MF_R];
+        auto fetch = [&](int g0) {                   // unconditional, clamped: all requests of a block in flight
+#pragma unroll
+            for (int i = 0; i < MF_R; ++i) {
+                const int g = g0 + sub + i * sp.L;
+                const bool ok = live && g < G;
+                const float *pg = ps + (size_t)(ok ? g : 0) * 3 * C;
+                const float m_ = pg[0], q_ = pg[C], n_ = pg[2 * C];
+                pm[i] = m_;
+                pq[i] = q_;
+                pn[i] = ok ? n_ : 0.0f;              // a partial with n = 0 adds nothing to either pass
+            }
+        };
         // pass 1: N and the weighted mean
         double n = 0.0, sm = 0.0;
-        for (int g = lane; g < G; g += 64) {
-            const double ng = ps[((size_t)g * 3 + 2) * C + c];
-            n += ng;
-            sm += ng * (double)ps[((size_t)g * 3 + 0) * C + c];
+        for (int g0 = 0; g0 < G; g0 += sp.L * MF_R) {
+            fetch(g0);
+#pragma unroll
+            for (int i = 0; i < MF_R; ++i) {
+                n += (double)pn[i];
+                sm += (double)pn[i] * (double)pm[i];
+            }
         }
-        const double N = mf_wave_sum(n);
-        const double m = N > 0.0 ? mf_wave_sum(sm) / N : 0.0;
+        const double N = mf_group_sum(n, sp.L);
+        const double m = N > 0.0 ? mf_group_sum(sm, sp.L) / N : 0.0;
         // pass 2: M2 = sum M2_g + n_g (mean_g - mean)^2
         double q = 0.0;
-        for (int g = lane; g < G; g += 64) {
-            const double ng = ps[((size_t)g * 3 + 2) * C + c];
-            const double d = (double)ps[((size_t)g * 3 + 0) * C + c] - m;
-            q += (double)ps[((size_t)g * 3 + 1) * C + c] + ng * d * d;
+        for (int g0 = 0; g0 < G; g0 += sp.L * MF_R) {
+            if (!fits) fetch(g0);
+#pragma unroll
+            for (int i = 0; i < MF_R; ++i) {
+                const double d = (double)pm[i] - m;
+                q += pn[i] > 0.0f ? (double)pq[i] + (double)pn[i] * d * d : 0.0;
+            }
         }
-        double var = N > 0.0 ? mf_wave_sum(q) / N : 0.0;          // biased
+        double var = N > 0.0 ? mf_group_sum(q, sp.L) / N : 0.0;          // biased
         var = var < 0.0 ? 0.0 : var;
         const float mu = (float)m, rs = (float)(1.0 / sqrt(var + (double)eps));
-        if (running_mean) {
-            const double unbiased = N > 1.0 ? var * N / (N - 1.0) : var;
-            const double shift = mean_shift ? (double)mean_shift[c] : 0.0;
-            rmean = (float)((1.0 - momentum) * rmean + momentum * (m + shift));
-            rvar = (float)((1.0 - momentum) * rvar + momentum * unbiased);
-        }
-        if (lane == 0) {
+        if (live && sub == 0) {
             if (mean) mean[(size_t)seg * C + c] = mu;
             if (rstd) rstd[(size_t)seg * C + c] = rs;
             if (ci_out) {
                 const float a = (gamma ? gamma[c] : 1.0f) * rs;
                 float *o = ci_out + (size_t)seg * 4 * C + c;
                 o[0] = a; o[C] = (beta ? beta[c] : 0.0f) - mu * a; o[2 * C] = mu; o[3 * C] = rs;
+            }
+        }
+        if (running_mean) {                          // in call order: the running statistics chain
+            const int last = nseg - seg0 < sp.SP ? nseg - seg0 : sp.SP;
+            for (int k = 0; k < last; ++k) {
+                const double Nk = mf_readlane(N, k * sp.L), mk = mf_readlane(m, k * sp.L), vk = mf_readlane(var, k * sp.L);
+                const double unbiased = Nk > 1.0 ? vk * Nk / (Nk - 1.0) : vk;
+                rmean = (float)((1.0 - momentum) * rmean + momentum * (mk + shift));
+                rvar = (float)((1.0 - momentum) * rvar + momentum * unbiased);
             }
         }
     }
@@ -684,22 +734,42 @@ __global__ __launch_bounds__(ML_THREADS) void mlp_bwd_finalize_kernel(const floa
                                                                       float *__restrict__ dbeta,
                                                                       const float *__restrict__ ci,
                                                                       float *__restrict__ cb) {
-    // one wave per channel, lanes over the partials (see mlp_stats_finalize_kernel)
+    // one wave per channel, a lane group per segment (see mlp_stats_finalize_kernel)
     const int lane = threadIdx.x & 63;
     const int c = blockIdx.x * MF_CH + (threadIdx.x >> 6);
     if (c >= C) return;
+    const MfSplit sp = mf_split(nseg);
+    const int grp = lane / sp.L, sub = lane - grp * sp.L;
     double ts = 0.0, tsx = 0.0;
-    for (int seg = 0; seg < nseg; ++seg) {
-        const float *ps = part + (size_t)seg * G * 2 * C;
+    for (int seg0 = 0; seg0 < nseg; seg0 += sp.SP) {
+        const int seg = seg0 + grp;
+        const bool live = seg < nseg;
+        const int segc = live ? seg : nseg - 1;
+        const float *ps = part + (size_t)segc * G * 2 * C + c;
+        const float rs = rstd[(size_t)segc * rstd_stride + c];
         double a0 = 0.0, a1 = 0.0;
-        for (int g = lane; g < G; g += 64) {
-            a0 += ps[((size_t)g * 2 + 0) * C + c];
-            a1 += ps[((size_t)g * 2 + 1) * C + c];
+        for (int g0 = 0; g0 < G; g0 += sp.L * MF_R) {
+            float v0[MF_R], v1[MF_R];
+#pragma unroll
+            for (int i = 0; i < MF_R; ++i) {         // unconditional, clamped: all requests of a block in flight
+                const int g = g0 + sub + i * sp.L;
+                const bool ok = live && g < G;
+                const float *pg = ps + (size_t)(ok ? g : 0) * 2 * C;
+                const float x0 = pg[0], x1 = pg[C];
+                v0[i] = ok ? x0 : 0.0f;
+                v1[i] = ok ? x1 : 0.0f;
+            }
+#pragma unroll
+            for (int i = 0; i < MF_R; ++i) {
+                a0 += (double)v0[i];
+                a1 += (double)v1[i];
+            }
         }
-        const double s = mf_wave_sum(a0), sx = mf_wave_sum(a1) * (double)rstd[(size_t)seg * rstd_stride + c];
-        ts += s;
-        tsx += sx;
-        if (lane == 0) {
+        const double s = mf_group_sum(a0, sp.L), sx = mf_group_sum(a1, sp.L) * (double)rs;
+        const bool owner = live && sub == 0;
+        ts += mf_wave_sum(owner ? s : 0.0);          // fixed order over the segments of the sweep
+        tsx += mf_wave_sum(owner ? sx : 0.0);
+        if (owner) {
             const float c1 = (float)(s / (double)P), c2 = (float)(sx / (double)P);
             if (c12) {
                 c12[((size_t)seg * 2 + 0) * C + c] = c1;

@@ -203,32 +203,58 @@ __device__ __forceinline__ void block_column_reduce(float (&acc)[NQ][NE], int cp
     }
 }
 
-// Sum the per-workgroup partials of two quantities: a workgroup is ONE wave that owns FIN_CH channels, each
-// summed by 64/FIN_CH lanes over the partial rows (a handful of independent loads per lane, not a 64-deep
-// dependent chain), then an fp64 butterfly over those lanes -- no LDS and no barrier (the LDS tree this replaces
-// was seven barriers per segment, and the segments of a launch run back to back in one workgroup).
-// True in the lane that owns channel c.
+// Sums of the per-workgroup partials of two quantities, for every segment of a launch: one WAVE per channel
+// (FIN_CH channels per workgroup), its lanes split into groups, one per segment (SP segments per sweep, a power
+// of two; L = 64 / SP lanes each), so that the segments' partials travel side by side and the launch waits for
+// memory once per sweep instead of once per segment.  fp64, fixed butterflies, no LDS and no barrier.
 constexpr int FIN_CH = 4;
-constexpr int FIN_THREADS = 64;
-constexpr int FIN_LANES = FIN_THREADS / FIN_CH;
-__device__ __forceinline__ bool finalize_sums(const float *__restrict__ part, int G, int C, int &c, double &s0,
-                                              double &s1) {
-    const int cl = threadIdx.x % FIN_CH, gl = threadIdx.x / FIN_CH;
-    c = blockIdx.x * FIN_CH + cl;
+constexpr int FIN_THREADS = 64 * FIN_CH;
+constexpr int FIN_R = 8;                       // requests in flight per lane and quantity
+struct FinSplit { int SP, L; };
+__device__ __forceinline__ FinSplit fin_split(int nseg) {
+    int sp = 1;
+    while (sp < nseg && sp < 64) sp <<= 1;
+    return {sp, 64 / sp};
+}
+__device__ __forceinline__ double fin_group_sum(double v, int L) {
+    for (int m = L >> 1; m > 0; m >>= 1) v += __shfl_xor(v, m, 64);
+    return v;
+}
+__device__ __forceinline__ double fin_wave_sum(double v) {
+#pragma unroll
+    for (int m = 32; m > 0; m >>= 1) v += __shfl_xor(v, m, 64);
+    return v;
+}
+__device__ __forceinline__ double fin_readlane(double v, int l) {          // l wave-uniform
+    const long long b = __double_as_longlong(v);
+    const int lo = __builtin_amdgcn_readlane((int)(unsigned)(b & 0xffffffffll), l);
+    const int hi = __builtin_amdgcn_readlane((int)(b >> 32), l);
+    return __longlong_as_double(((long long)hi << 32) | (long long)(unsigned)lo);
+}
+// the two sums of segment `seg` (clamped when the group has none: live == false) in every lane of its group
+__device__ __forceinline__ void finalize_sums(const float *__restrict__ ws, int seg, bool live, int sub, int L, int G,
+                                              int C, int c, double &s0, double &s1) {
+    const float *part = ws + WS_HEAD + (size_t)seg * BN_MAX_BLOCKS * 2 * C + c;
     double a0 = 0.0, a1 = 0.0;
-    if (c < C)
-        for (int g = gl; g < G; g += FIN_LANES) {
-            a0 += part[((size_t)g * 2 + 0) * C + c];
-            a1 += part[((size_t)g * 2 + 1) * C + c];
+    for (int g0 = 0; g0 < G; g0 += L * FIN_R) {
+        float v0[FIN_R], v1[FIN_R];
+#pragma unroll
+        for (int i = 0; i < FIN_R; ++i) {      // unconditional, clamped: all requests of a block in flight
+            const int g = g0 + sub + i * L;
+            const bool ok = live && g < G;
+            const float *pg = part + (size_t)(ok ? g : 0) * 2 * C;
+            const float x0 = pg[0], x1 = pg[C];
+            v0[i] = ok ? x0 : 0.0f;
+            v1[i] = ok ? x1 : 0.0f;
         }
 #pragma unroll
-    for (int m = FIN_CH; m < FIN_THREADS; m <<= 1) {      // fixed butterfly over the lanes of one channel
-        a0 += __shfl_xor(a0, m, 64);
-        a1 += __shfl_xor(a1, m, 64);
+        for (int i = 0; i < FIN_R; ++i) {
+            a0 += (double)v0[i];
+            a1 += (double)v1[i];
+        }
     }
-    s0 = a0;
-    s1 = a1;
-    return gl == 0 && c < C;
+    s0 = fin_group_sum(a0, L);
+    s1 = fin_group_sum(a1, L);
 }
 
 // ------------------------------------------------------------------ forward statistics
@@ -280,25 +306,39 @@ __global__ __launch_bounds__(FIN_THREADS) void rowbn_stats_finalize_kernel(
     long long *__restrict__ num_batches_tracked, const float *__restrict__ mean_shift, float *__restrict__ mean,
     float *__restrict__ rstd, int nseg) {
     if (num_batches_tracked && blockIdx.x == 0 && threadIdx.x == 0) *num_batches_tracked += nseg;
-    for (int seg = 0; seg < nseg; ++seg) {     // in call order: the running statistics chain
-        int c;
+    const int lane = threadIdx.x & 63;
+    const int c = blockIdx.x * FIN_CH + (threadIdx.x >> 6);
+    if (c >= C) return;                        // whole wave
+    const FinSplit sp = fin_split(nseg);
+    const int grp = lane / sp.L, sub = lane - grp * sp.L;
+    float rmean = running_mean ? running_mean[c] : 0.0f, rvar = running_mean ? running_var[c] : 0.0f;
+    const double shift = mean_shift ? (double)mean_shift[c] : 0.0;   // see tpgan_ops.h
+    for (int seg0 = 0; seg0 < nseg; seg0 += sp.SP) {
+        const int seg = seg0 + grp;
+        const bool live = seg < nseg;
+        const int segc = live ? seg : nseg - 1;
         double s, ss;
-        const bool mine = finalize_sums(ws + WS_HEAD + (size_t)seg * BN_MAX_BLOCKS * 2 * C, G, C, c, s, ss);
-        if (mine) {
-            const double piv = Chunk<T, BnElems<T>::NE>::one(x + (size_t)seg * P * C + c);
-            const double m = s / (double)P;
-            double var = ss / (double)P - m * m;  // biased, about the pivot
-            var = var < 0.0 ? 0.0 : var;
+        finalize_sums(ws, segc, live, sub, sp.L, G, C, c, s, ss);
+        const double piv = Chunk<T, BnElems<T>::NE>::one(x + (size_t)segc * P * C + c);
+        const double m = s / (double)P;
+        double var = ss / (double)P - m * m;  // biased, about the pivot
+        var = var < 0.0 ? 0.0 : var;
+        if (live && sub == 0) {
             mean[(size_t)seg * C + c] = (float)(piv + m);
             rstd[(size_t)seg * C + c] = (float)(1.0 / sqrt(var + (double)eps));
-            if (running_mean) {
-                const double unbiased = P > 1 ? var * (double)P / (double)(P - 1) : var;
-                const double shift = mean_shift ? (double)mean_shift[c] : 0.0;   // see tpgan_ops.h
-                running_mean[c] = (float)((1.0 - momentum) * running_mean[c] + momentum * (piv + m + shift));
-                running_var[c] = (float)((1.0 - momentum) * running_var[c] + momentum * unbiased);
+        }
+        if (running_mean) {                    // in call order: the running statistics chain
+            const int last = nseg - seg0 < sp.SP ? nseg - seg0 : sp.SP;
+            const double pm = piv + m;
+            for (int k = 0; k < last; ++k) {
+                const double mk = fin_readlane(pm, k * sp.L), vk = fin_readlane(var, k * sp.L);
+                const double unbiased = P > 1 ? vk * (double)P / (double)(P - 1) : vk;
+                rmean = (float)((1.0 - momentum) * rmean + momentum * (mk + shift));
+                rvar = (float)((1.0 - momentum) * rvar + momentum * unbiased);
             }
         }
     }
+    if (running_mean && lane == 0) { running_mean[c] = rmean; running_var[c] = rvar; }
 }
 
 // ------------------------------------------------------------------ forward apply (+max)
@@ -482,21 +522,27 @@ __global__ __launch_bounds__(FIN_THREADS) void rowbn_bwd_finalize_kernel(const f
                                                                         float *__restrict__ dgamma,
                                                                         float *__restrict__ dbeta,
                                                                         float *__restrict__ c12, int nseg) {
+    const int lane = threadIdx.x & 63;
+    const int c = blockIdx.x * FIN_CH + (threadIdx.x >> 6);
+    if (c >= C) return;                        // whole wave
+    const FinSplit sp = fin_split(nseg);
+    const int grp = lane / sp.L, sub = lane - grp * sp.L;
     double ts = 0.0, tsx = 0.0;
-    int c = 0;
-    bool mine = false;
-    for (int seg = 0; seg < nseg; ++seg) {
+    for (int seg0 = 0; seg0 < nseg; seg0 += sp.SP) {
+        const int seg = seg0 + grp;
+        const bool live = seg < nseg;
         double s, sx;
-        mine = finalize_sums(ws + WS_HEAD + (size_t)seg * BN_MAX_BLOCKS * 2 * C, G, C, c, s, sx);
-        if (mine) {
-            ts += s;                               // fixed order: segment after segment
-            tsx += sx;
+        finalize_sums(ws, live ? seg : nseg - 1, live, sub, sp.L, G, C, c, s, sx);
+        const bool owner = live && sub == 0;
+        ts += fin_wave_sum(owner ? s : 0.0);   // fixed order over the segments of the sweep
+        tsx += fin_wave_sum(owner ? sx : 0.0);
+        if (owner) {
             float *cs = c12 + (size_t)seg * 2 * C;
             cs[c] = training ? (float)(s / (double)P) : 0.0f;       // eval-mode BN: no batch terms
             cs[C + c] = training ? (float)(sx / (double)P) : 0.0f;
         }
     }
-    if (!mine) return;
+    if (lane != 0) return;
     if (dbeta) dbeta[c] = (float)ts;
     if (dgamma) dgamma[c] = (float)tsx;
 }

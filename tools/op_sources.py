@@ -7,7 +7,6 @@ autograd nodes of the backward side).
     python tools/op_sources.py [op substring ...]     # default: copy_ _to_copy div add cat fill mm
 """
 import collections
-import importlib.util
 import os
 import sys
 import traceback
@@ -18,20 +17,18 @@ import numpy as np
 import torch
 from torch.utils._python_dispatch import TorchDispatchMode
 
-spec = importlib.util.spec_from_file_location("bench", os.path.join(ROOT, "bench.py"))
-b = importlib.util.module_from_spec(spec)
-argv, sys.argv = sys.argv, ["bench.py"]
-spec.loader.exec_module(b)
+import tpgan_amd  # noqa: F401,E402
+from tpgan_amd import configs  # noqa: E402
+
+argv = sys.argv
 wanted = argv[1:] or ["copy_", "_to_copy", "div", "add", "cat", "fill", "mm", "zeros", "ones", "clone", "leaky"]
 
 torch.backends.cudnn.enabled = False
 dev = torch.device("cuda", 0)
 np.random.seed(0)
-models = b.build(dev, capturable=True)
-clips = [b.fluid_clip(8, 4096, 8, 3, seed=s, device=dev) for s in range(2)]
-from tpgan_amd.gan_step_graph import GraphedFluidStep
-G, Ds, Dt, opts = models
-step = GraphedFluidStep(G, Ds, Dt, opts, b.OPT, clips[0][0], clips[0][1], 1.0, torch.bfloat16, None)
+models = configs.build_models("cfg2", dev, capturable=True)
+clips = [configs.make_clip("cfg2", seed=s, device=dev) for s in range(2)]
+step = configs.graphed_step("cfg2", models, clips[0], amp_dtype=torch.bfloat16)
 step._load(*clips[1])
 step._run_eager(True)
 torch.cuda.synchronize()
