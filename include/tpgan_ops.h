@@ -264,7 +264,10 @@ int tpg_mlp_fwd(const void *x, long long P, int Cin, int Cout, int nseg, const f
  * tpg_mlp_wgrad: dW (nseg,Cout,Cin) f32 = dx_out^T . lrelu(BN_in(x_in)), both operands rebuilt from the
  *   saved rows, staged in LDS and read transposed (ds_read_b64_tr_b16); per-workgroup fp32 slabs summed
  *   in fixed order (bitwise reproducible).  ws: tpg_mlp_wgrad_workspace_bytes(P, Cin, Cout, nseg).
- * tpg_mlp_bn_bwd_apply: dx = a*(g - c1 - xhat*c2) for the tail's first BatchNorm (g already activated). */
+ * tpg_mlp_bn_bwd_apply: dx = a*(g - c1 - xhat*c2) for the tail's first BatchNorm (g already activated).
+ * tpg_mlp_bn_bwd_apply_rowsum: the same, plus qneg (nseg * P/K, C) f32 = -sum over each group of K consecutive rows of
+ *   the stored (bf16-rounded) dx, k ascending: what tpg_rowcombine_bwd(mode SUB) computes as gQE from those rows --
+ *   pass it there as gQE_ready and the rows are not read a second time. */
 int tpg_mlp_consts(const float *mean, const float *rstd, const float *gamma, const float *beta, const float *c12,
                    int C, int nseg, float *ci, float *cb, void *stream);
 int tpg_mlp_max_prep(const void *gout, const void *y, const float *cb_out, float slope_out, long long rows, int C,
@@ -279,6 +282,8 @@ int tpg_mlp_wgrad(const void *x_out, const void *g_out, const uint8_t *arg, int 
                   int Cout, int nseg, int mode, float *dW, void *ws, void *stream);
 int tpg_mlp_bn_bwd_apply(const void *g, const void *x, const float *ci, const float *c12, long long P, int C,
                          int nseg, void *dx, void *stream);
+int tpg_mlp_bn_bwd_apply_rowsum(const void *g, const void *x, const float *ci, const float *c12, long long P, int K,
+                                int C, int nseg, void *dx, float *qneg, void *stream);
 
 /* ---- fused spectral normalisation of a (R x Cn) conv / linear weight ------------------------
  * torch.nn.utils.spectral_norm's forward pre-hook (n_power_iterations = 1) on every conv and

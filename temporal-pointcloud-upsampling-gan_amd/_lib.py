@@ -51,6 +51,7 @@ SIGNATURES = {
     "tpg_mlp_dgrad": [_P, _P, _P, _I, _P, _P, _P, _F, _P, _I, _L, _I, _I, _I, _I, _P, _P, _P, _P, _P, _P, _P],
     "tpg_mlp_wgrad": [_P, _P, _P, _I, _P, _P, _P, _F, _L, _I, _I, _I, _I, _P, _P, _P],
     "tpg_mlp_bn_bwd_apply": [_P, _P, _P, _P, _L, _I, _I, _P, _P],
+    "tpg_mlp_bn_bwd_apply_rowsum": [_P, _P, _P, _P, _L, _I, _I, _I, _P, _P, _P],
     "tpg_small_tail_fwd": [_P, _I, _P, _P, _F, _F, _L, _I, _I, _I, _I, _P, _P, _P],
     "tpg_small_tail_bwd": [_P, _P, _P, _P, _I, _P, _P, _F, _F, _L, _I, _I, _I, _I, _P, _P, _P, _P, _P],
     "tpg_mlp_fwd": [_P, _L, _I, _I, _I, _P, _I, _F, _P, _I, _P, _F, _F, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P],

@@ -1066,6 +1066,73 @@ __global__ __launch_bounds__(ML_THREADS) void mlp_bn_bwd_apply_kernel(
     }
 }
 
+// The same with the row sums the row gather's backward needs next (ROW_SUB: gQ[s] = -sum_k dx[s,k], tpg_rowcombine_bwd):
+// a thread owns one 8-channel chunk of one GROUP of K consecutive rows, so the sum is its own -- of the ROUNDED bf16
+// values, k ascending, bit for bit what rowsum_neg_kernel makes of the stored rows, without reading them again.
+// qneg (nseg * P/K, C) f32.
+__global__ __launch_bounds__(ML_THREADS) void mlp_bn_bwd_apply_rowsum_kernel(
+    const __hip_bfloat16 *__restrict__ g, const __hip_bfloat16 *__restrict__ x, long long P, int K, int C,
+    const float *__restrict__ ci, const float *__restrict__ c12, __hip_bfloat16 *__restrict__ dx,
+    float *__restrict__ qneg) {
+    const int cpr = C / 8, gpi = ML_THREADS / cpr;
+    const int chunk = threadIdx.x % cpr, gsub = threadIdx.x / cpr, col = chunk * 8;
+    if (gsub >= gpi) return;
+    const int seg = blockIdx.y;
+    const long long groups = P / K;
+    g += (size_t)seg * P * C;
+    x += (size_t)seg * P * C;
+    dx += (size_t)seg * P * C;
+    qneg += (size_t)seg * groups * C;
+    float a[8], mu[8], rs[8], c1[8], c2[8];
+    ld8(ci + ((size_t)seg * 4 + 0) * C + col, a);
+    ld8(ci + ((size_t)seg * 4 + 2) * C + col, mu);
+    ld8(ci + ((size_t)seg * 4 + 3) * C + col, rs);
+    ld8(c12 + ((size_t)seg * 2 + 0) * C + col, c1);
+    ld8(c12 + ((size_t)seg * 2 + 1) * C + col, c2);
+    float e[8], f[8];
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {           // dx = a*g + e - f*x
+        f[i] = a[i] * rs[i] * c2[i];
+        e[i] = a[i] * (mu[i] * rs[i] * c2[i] - c1[i]);
+    }
+    for (long long s = (long long)blockIdx.x * gpi + gsub; s < groups; s += (long long)gridDim.x * gpi) {
+        const size_t base = (size_t)s * K * C + col;
+        float acc[8];
+#pragma unroll
+        for (int i = 0; i < 8; ++i) acc[i] = 0.0f;
+        auto one = [&](const uint4 gv, const uint4 xv, size_t off) {
+            const unsigned gw[4] = {gv.x, gv.y, gv.z, gv.w}, xw[4] = {xv.x, xv.y, xv.z, xv.w};
+            unsigned o[4];
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                const float v0 = __builtin_fmaf(a[2 * i], bf16_lo(gw[i]), __builtin_fmaf(-f[2 * i], bf16_lo(xw[i]), e[2 * i]));
+                const float v1 = __builtin_fmaf(a[2 * i + 1], bf16_hi(gw[i]), __builtin_fmaf(-f[2 * i + 1], bf16_hi(xw[i]), e[2 * i + 1]));
+                o[i] = pack_bf16x2(v0, v1);
+                acc[2 * i] -= bf16_lo(o[i]);
+                acc[2 * i + 1] -= bf16_hi(o[i]);
+            }
+            *reinterpret_cast<uint4 *>(dx + off) = make_uint4(o[0], o[1], o[2], o[3]);
+        };
+        int k = 0;
+        for (; k + 4 <= K; k += 4) {
+            uint4 gv[4], xv[4];
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                gv[u] = *reinterpret_cast<const uint4 *>(g + base + (size_t)(k + u) * C);
+                xv[u] = *reinterpret_cast<const uint4 *>(x + base + (size_t)(k + u) * C);
+            }
+#pragma unroll
+            for (int u = 0; u < 4; ++u) one(gv[u], xv[u], base + (size_t)(k + u) * C);
+        }
+        for (; k < K; ++k)
+            one(*reinterpret_cast<const uint4 *>(g + base + (size_t)k * C), *reinterpret_cast<const uint4 *>(x + base + (size_t)k * C),
+                base + (size_t)k * C);
+        float *q = qneg + (size_t)s * C + col;
+        *reinterpret_cast<float4 *>(q) = make_float4(acc[0], acc[1], acc[2], acc[3]);
+        *reinterpret_cast<float4 *>(q + 4) = make_float4(acc[4], acc[5], acc[6], acc[7]);
+    }
+}
+
 template <int CIN, int COUT> constexpr int fwd_strips() {
     // two 16-row strips per wave while the accumulators (STRIPS * COUT/16 * 4 registers) and the
     // double-buffered A fragments (2 * STRIPS * CIN/32 * 4) leave two workgroups per CU room
@@ -1340,6 +1407,29 @@ extern "C" int tpg_mlp_bn_bwd_apply(const void *g, const void *x, const float *c
     hipLaunchKernelGGL(mlp_bn_bwd_apply_kernel, dim3((unsigned)b, nseg), dim3(ML_THREADS), 0, tpg_stream(stream),
                        static_cast<const __hip_bfloat16 *>(g), static_cast<const __hip_bfloat16 *>(x), P, C, ci, c12,
                        static_cast<__hip_bfloat16 *>(dx));
+    TPG_RETURN_IF_LAUNCH_FAILED();
+    return TPG_OK;
+}
+
+extern "C" int tpg_mlp_bn_bwd_apply_rowsum(const void *g, const void *x, const float *ci, const float *c12, long long P,
+                                           int K, int C, int nseg, void *dx, float *qneg, void *stream) {
+    if (P <= 0 || K <= 0 || nseg < 1 || nseg > 65535 || P % nseg || (P / nseg) % K || !g || !x || !ci || !c12 || !dx || !qneg)
+        return TPG_ERR_ARG;
+    if (C <= 0 || C % 8 || C > 2048) return TPG_ERR_UNSUPPORTED;
+    if ((reinterpret_cast<uintptr_t>(g) | reinterpret_cast<uintptr_t>(x) | reinterpret_cast<uintptr_t>(dx) |
+         reinterpret_cast<uintptr_t>(qneg)) & 15)
+        return TPG_ERR_UNSUPPORTED;
+    P /= nseg;
+    const int gpi = ML_THREADS / (C / 8);
+    long long b = (P / K + gpi - 1) / gpi;
+    // one round of resident workgroups over all segments (six segments at 256 each were a round and a half: 153 us
+    // where the plain kernel took 118)
+    static const long long slots = [] { const char *e = getenv("TPG_BNROWSUM_SLOTS"); return e ? atoll(e) : 1024ll; }();
+    const long long cap = slots / nseg > 0 ? slots / nseg : 1;
+    b = b < 1 ? 1 : (b > cap ? cap : b);
+    hipLaunchKernelGGL(mlp_bn_bwd_apply_rowsum_kernel, dim3((unsigned)b, nseg), dim3(ML_THREADS), 0, tpg_stream(stream),
+                       static_cast<const __hip_bfloat16 *>(g), static_cast<const __hip_bfloat16 *>(x), P, K, C, ci, c12,
+                       static_cast<__hip_bfloat16 *>(dx), qneg);
     TPG_RETURN_IF_LAUNCH_FAILED();
     return TPG_OK;
 }

@@ -572,9 +572,16 @@ class HipBackend:
                    flops=2 * E * (2 * H * C1 + 2 * C1 * C2 + H * C1))
         return gh, dW1, dW2
 
-    def mlp_bn_bwd_apply(self, g, x, ci, c12, nseg):
+    def mlp_bn_bwd_apply(self, g, x, ci, c12, nseg, K=0):
+        """dx of the tail's first BatchNorm; K > 0: also qneg (P/K, C) f32 = -sum over each group of K rows of dx
+        (the ROW_SUB gather's gradient of Q, see _RowCombine.backward) -> (dx, qneg)."""
         P, Cc = x.shape
         dx = torch.empty_like(x)
+        if K:
+            qneg = torch.empty((P // K, Cc), dtype=torch.float32, device=x.device)
+            self._call("tpg_mlp_bn_bwd_apply_rowsum", "mlp_bn_bwd_apply", 6 * P * Cc + 4 * (P // K) * Cc, x, _ptr(g),
+                       _ptr(x), _ptr(ci), _ptr(c12), P, K, Cc, nseg, _ptr(dx), _ptr(qneg))
+            return dx, qneg
         self._call("tpg_mlp_bn_bwd_apply", "mlp_bn_bwd_apply", 6 * P * Cc, x, _ptr(g), _ptr(x), _ptr(ci), _ptr(c12), P,
                    Cc, nseg, _ptr(dx))
         return dx
@@ -937,6 +944,39 @@ def chamfer_nn(src, tgt):
 ROW_GATHER, ROW_SUB, ROW_EDGE = 0, 1, 2
 
 
+# Hand-off between two autograd nodes: a fused tail's backward (_MlpTail) writes its input gradient dx0 group by group
+# and has each group's row sum in registers; when dx0 then arrives at the ROW_SUB gather that made the tail's input,
+# that node needs exactly those sums (gQ[s] = -sum_k dx0[s,k]) and would read all of dx0 again for them.  The slot
+# holds (dx0, qneg, K) of the LAST tail backward -- a strong reference, so dx0's memory cannot have been handed to
+# another tensor while the slot is full, and "same pointer, size and type" means "these very rows".  A gradient that
+# was accumulated with another (a new tensor) or anything else simply does not match and takes the ordinary path.
+_ROWSUM_SLOT = [None]
+_ROWSUM_HANDOFF = [os.environ.get("TPG_ROWSUM_HANDOFF", "1") != "0"]
+
+
+def set_rowsum_handoff(flag):
+    """A/B and test switch for the hand-off above; returns the previous setting."""
+    prev, _ROWSUM_HANDOFF[0] = _ROWSUM_HANDOFF[0], bool(flag)
+    _ROWSUM_SLOT[0] = None
+    return prev
+
+
+def _offer_rowsum(dx0, qneg, K):
+    _ROWSUM_SLOT[0] = (dx0, qneg, K)
+
+
+def _take_rowsum(gout):
+    """qneg if gout (B,S,K,C) is the dx0 of the slot, else None; empties the slot either way."""
+    slot, _ROWSUM_SLOT[0] = _ROWSUM_SLOT[0], None
+    if slot is None:
+        return None
+    dx0, qneg, K = slot
+    if (gout.data_ptr() == dx0.data_ptr() and gout.numel() == dx0.numel() and gout.dtype == dx0.dtype
+            and gout.dim() == 4 and gout.shape[2] == K and gout.shape[3] == dx0.shape[1]):
+        return qneg
+    return None
+
+
 class _RowCombine(torch.autograd.Function):
     @staticmethod
     def forward(ctx, U, QE, idx, mode, slope, out_dtype, inverse):
@@ -955,6 +995,12 @@ class _RowCombine(torch.autograd.Function):
         if gout.dtype not in _DTYPE_CODE:
             gout = gout.float()
         kw = {} if ctx.inverse is None else {"inverse": ctx.inverse}
+        ready = _take_rowsum(gout) if (ctx.mode == ROW_SUB and ctx.in_dtype == torch.float32) else None
+        if ready is not None:
+            # the producer of gout (a fused tail's backward) has summed its rows over k already: what is left of the
+            # SUB backward is the plain gather's scatter
+            gU, _ = backend_for(gout).rowcombine_bwd(gout, idx, None, ROW_GATHER, ctx.N, ctx.slope, ctx.in_dtype, **kw)
+            return gU, (ready.view(gout.shape[0], gout.shape[1], gout.shape[3]) if ctx.has_q else None), None, None, None, None, None
         gU, gQE = backend_for(gout).rowcombine_bwd(gout, idx, E, ctx.mode, ctx.N, ctx.slope, ctx.in_dtype, **kw)
         return gU, (gQE if ctx.has_q else None), None, None, None, None, None
 
@@ -1179,7 +1225,12 @@ class _MlpTail(torch.autograd.Function):
                                                  slopes[l - 1], Ws[l - 1], nseg, need_aff[l - 1])
             grads_aff[l - 1] = (dg, db)
             g_next, arg_next, K_next = g_in, None, 0
-        dx0 = be.mlp_bn_bwd_apply(g_next, xs[0], cis[0], c12, nseg) if need[0] else None
+        dx0 = None
+        if need[0] and K and _ROWSUM_HANDOFF[0]:
+            dx0, qneg = be.mlp_bn_bwd_apply(g_next, xs[0], cis[0], c12, nseg, K)
+            _offer_rowsum(dx0, qneg, K)              # for the ROW_SUB gather this tail's input came from, if any
+        elif need[0]:
+            dx0 = be.mlp_bn_bwd_apply(g_next, xs[0], cis[0], c12, nseg)
         res = [dx0, None, grads_aff[0][0], grads_aff[0][1]]
         for l in range(L):
             gw = grads_w[l]

@@ -98,3 +98,8 @@ def test_new_entries_reject_bad_arguments_before_any_launch(hip_lib):
     assert hip_lib.tpg_small_tail_fwd(p, 0, p, p, 0.2, 0.2, 16, 0, 16, 16, 32, p, p, None) == -1
     assert hip_lib.tpg_small_tail_fwd(p, 0, p, p, 0.2, 0.2, 0, 4, 16, 16, 32, p, p, None) == 0
     assert hip_lib.tpg_small_tail_workspace_bytes(12288, 20) > 0 and hip_lib.tpg_frnn_grid_workspace_bytes(0, 8) == 0
+    # BatchNorm backward + row sums: whole groups of K rows per segment, channel chunks of 8
+    assert hip_lib.tpg_mlp_bn_bwd_apply_rowsum(p, p, p, p, 64, 5, 64, 1, p, p, None) == -1       # 64 rows, K = 5
+    assert hip_lib.tpg_mlp_bn_bwd_apply_rowsum(p, p, p, p, 64, 0, 64, 1, p, p, None) == -1
+    assert hip_lib.tpg_mlp_bn_bwd_apply_rowsum(p, p, p, p, 64, 8, 64, 1, p, None, None) == -1
+    assert hip_lib.tpg_mlp_bn_bwd_apply_rowsum(p, p, p, p, 64, 8, 60, 1, p, p, None) == -3

@@ -196,6 +196,45 @@ def test_mlp_tail_is_bitwise_reproducible():
         assert torch.equal(a, b)
 
 
+@pytest.mark.parametrize("C,K,S,nseg", [(64, 32, 256, 1), (64, 12, 300, 2), (128, 7, 96, 3)])
+def test_tail_hands_its_row_sums_to_the_gather_that_fed_it(C, K, S, nseg):
+    """A set-abstraction level is row_combine(ROW_SUB) -> fused tail.  The tail's backward sums its input gradient
+    over each group of K rows while writing it (tpg_mlp_bn_bwd_apply_rowsum) and the gather's backward takes those
+    sums as the gradient of Q instead of reading the rows again: same bits as the two-pass route, and a gradient
+    that is NOT the tail's own tensor (here: accumulated with a second consumer's) must not pick the sums up."""
+    import tpgan_amd.ops as ops
+    torch.manual_seed(C + K)
+    B, N = 2 * nseg, 500
+    U0 = torch.randn(B, N, C, device="cuda")
+    Q0 = torch.randn(B, S, C, device="cuda")
+    idx = torch.randint(0, N, (B, S, K), device="cuda", dtype=torch.int32)
+    W = (torch.randn(128, C) / C ** 0.5).cuda().requires_grad_(True)
+    prev_det = ops.set_deterministic(True)            # lists in entry order: the scatter sums are reproducible
+    try:
+        res = {}
+        for tag, handoff, second in (("two-pass", False, False), ("handed", True, False), ("shared", True, True)):
+            prev = ops.set_rowsum_handoff(handoff)
+            try:
+                bns = [torch.nn.BatchNorm1d(c).cuda().train() for c in (C, 128)]
+                U, Q = U0.clone().requires_grad_(True), Q0.clone().requires_grad_(True)
+                y = ops.row_combine(U, Q, idx, ops.ROW_SUB, out_dtype=torch.bfloat16)
+                out = ops.mlp_tail(y.view(-1, C), bns, [W], [0.01, 0.01], K, nseg)
+                loss = (out.float() * torch.linspace(-1, 1, out.numel(), device="cuda").view_as(out)).sum()
+                if second:
+                    loss = loss + y.float().square().sum() * 1e-3
+                res[tag] = torch.autograd.grad(loss, [U, Q])
+                assert ops._ROWSUM_SLOT[0] is None or second        # taken (and emptied) by the gather's backward
+            finally:
+                ops.set_rowsum_handoff(prev)
+    finally:
+        ops.set_deterministic(prev_det)
+    for a, b in zip(res["two-pass"], res["handed"]):
+        assert torch.equal(a, b)
+    # the shared case went the ordinary way: finite, and different from the tail-only gradient
+    assert all(torch.isfinite(t).all() for t in res["shared"])
+    assert not torch.equal(res["shared"][1], res["handed"][1])
+
+
 # ------------------------------------------------------------------ EdgeConv MLP: the tail without BatchNorm
 @pytest.mark.parametrize("chain,K,P", [((64, 64, 128), 20, 512 * 20 * 6), ((128, 128, 256), 12, 512 * 12 * 4),
                                          ((128, 128, 256), 4, 1000 * 4), ((64, 128), 9, 9 * 333)])

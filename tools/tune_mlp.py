@@ -88,4 +88,6 @@ for name, P, nseg, Cin, Cout in SHAPES:
     g1 = torch.randn(P * nseg, Cin, device=dev).bfloat16()
     c12 = torch.rand(nseg, 2, Cin, device=dev)
     us = timeit(lambda: hip.mlp_bn_bwd_apply(g1, x_in, ci, c12, nseg))
-    print(f"{name:22s} bn_bwd_apply (C={Cin}) {us:8.1f} us {6 * P * nseg * Cin / us / 1e3:7.1f} GB/s")
+    us_r = timeit(lambda: hip.mlp_bn_bwd_apply(g1, x_in, ci, c12, nseg, K))
+    print(f"{name:22s} bn_bwd_apply (C={Cin}) {us:8.1f} us {6 * P * nseg * Cin / us / 1e3:7.1f} GB/s | with the row sums over K = {K} "
+          f"{us_r:8.1f} us {6 * P * nseg * Cin / us_r / 1e3:7.1f} GB/s")
