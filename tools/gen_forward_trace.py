@@ -4,7 +4,6 @@ line of this package that launched them, and times the same forward as a hipGrap
 
     python tools/gen_forward_trace.py
 """
-import importlib.util
 import os
 import sys
 
@@ -14,15 +13,13 @@ import numpy as np
 import torch
 from torch.profiler import ProfilerActivity, profile
 
-spec = importlib.util.spec_from_file_location("bench", os.path.join(ROOT, "bench.py"))
-b = importlib.util.module_from_spec(spec)
-argv, sys.argv = sys.argv, ["bench.py"]
-spec.loader.exec_module(b)
+import tpgan_amd  # noqa: F401,E402
+from tpgan_amd import configs  # noqa: E402
 
 dev = torch.device("cuda", 0)
 np.random.seed(0)
-G, Ds, Dt, opts = b.build(dev, capturable=True)
-low, high = b.fluid_clip(8, 4096, 8, 3, seed=0, device=dev)
+G, Ds, Dt, opts = configs.build_models("cfg2", dev, capturable=True)
+low, high = configs.make_clip("cfg2", seed=0, device=dev)
 stacked = torch.cat([low[1], low[0], low[2]], 0)
 
 
