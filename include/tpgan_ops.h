@@ -219,6 +219,19 @@ int tpg_rowbn_bwd_sums(const void *gy, int dtype_g, const void *x, int dtype_in,
                        const float *rstd, const float *gamma, const float *beta, float slope, float *dgamma,
                        float *dbeta, float *c12, void *ws, int nseg, void *stream);
 
+/* The statistics / sums launches above with the folded per-channel constants of the fused tail (tpg_mlp_consts)
+ * written by the SAME finalize launch -- a tail's first and last BatchNorm need no tpg_mlp_consts launch of their own:
+ *   tpg_rowbn_stats_consts   : phase STATS of tpg_rowbn_fwd (training mode) + ci (nseg,4,C) = sc | sh | mu | rs
+ *   tpg_rowbn_bwd_sums_consts: tpg_rowbn_bwd_sums + cb (nseg,4,C) = a | f*mu | e | f */
+int tpg_rowbn_stats_consts(const void *x, int dtype_in, long long P, int C, float eps, float momentum,
+                           float *running_mean, float *running_var, long long *num_batches_tracked,
+                           const float *mean_shift, const float *gamma, const float *beta, float *mean, float *rstd,
+                           float *ci, void *ws, int nseg, void *stream);
+int tpg_rowbn_bwd_sums_consts(const void *gy, int dtype_g, const void *x, int dtype_in, const uint8_t *argmax,
+                              const void *y, int dtype_y, long long P, int K, int C, int training, const float *mean,
+                              const float *rstd, const float *gamma, const float *beta, float slope, float *dgamma,
+                              float *dbeta, float *c12, float *cb, void *ws, int nseg, void *stream);
+
 /* ---- fused shared-MLP tail layer on MFMA tiles (csrc/mlp_fused.hip) --------------------------
  * The grouped-feature x MLP-weight contraction of set abstraction / flow embedding
  * (discriminator.py:63-78,140-148,276-282: conv1x1 -> BatchNorm2d -> LeakyReLU per layer) for one

@@ -304,7 +304,9 @@ __global__ __launch_bounds__(FIN_THREADS) void rowbn_stats_finalize_kernel(
     const T *__restrict__ x, const float *__restrict__ ws, int G, long long P, int C, float eps,
     float momentum, float *__restrict__ running_mean, float *__restrict__ running_var,
     long long *__restrict__ num_batches_tracked, const float *__restrict__ mean_shift, float *__restrict__ mean,
-    float *__restrict__ rstd, int nseg) {
+    float *__restrict__ rstd, int nseg, const float *__restrict__ gamma, const float *__restrict__ beta,
+    float *__restrict__ ci_out) {
+    // ci_out (nseg,4,C), optional: sc | sh | mu | rs of this BatchNorm as tpg_mlp_consts folds them (gamma / beta NULL = 1 / 0)
     if (num_batches_tracked && blockIdx.x == 0 && threadIdx.x == 0) *num_batches_tracked += nseg;
     const int lane = threadIdx.x & 63;
     const int c = blockIdx.x * FIN_CH + (threadIdx.x >> 6);
@@ -324,8 +326,14 @@ __global__ __launch_bounds__(FIN_THREADS) void rowbn_stats_finalize_kernel(
         double var = ss / (double)P - m * m;  // biased, about the pivot
         var = var < 0.0 ? 0.0 : var;
         if (live && sub == 0) {
-            mean[(size_t)seg * C + c] = (float)(piv + m);
-            rstd[(size_t)seg * C + c] = (float)(1.0 / sqrt(var + (double)eps));
+            const float mu = (float)(piv + m), rs = (float)(1.0 / sqrt(var + (double)eps));
+            mean[(size_t)seg * C + c] = mu;
+            rstd[(size_t)seg * C + c] = rs;
+            if (ci_out) {
+                const float a = (gamma ? gamma[c] : 1.0f) * rs;
+                float *o = ci_out + (size_t)seg * 4 * C + c;
+                o[0] = a; o[C] = (beta ? beta[c] : 0.0f) - mu * a; o[2 * C] = mu; o[3 * C] = rs;
+            }
         }
         if (running_mean) {                    // in call order: the running statistics chain
             const int last = nseg - seg0 < sp.SP ? nseg - seg0 : sp.SP;
@@ -521,7 +529,12 @@ __global__ __launch_bounds__(FIN_THREADS) void rowbn_bwd_finalize_kernel(const f
                                                                         long long P, int C, int training,
                                                                         float *__restrict__ dgamma,
                                                                         float *__restrict__ dbeta,
-                                                                        float *__restrict__ c12, int nseg) {
+                                                                        float *__restrict__ c12, int nseg,
+                                                                        const float *__restrict__ mean,
+                                                                        const float *__restrict__ rstd,
+                                                                        const float *__restrict__ gamma,
+                                                                        float *__restrict__ cb) {
+    // cb (nseg,4,C), optional: a | f*mu | e | f of this BatchNorm's backward as tpg_mlp_consts folds them
     const int lane = threadIdx.x & 63;
     const int c = blockIdx.x * FIN_CH + (threadIdx.x >> 6);
     if (c >= C) return;                        // whole wave
@@ -538,8 +551,16 @@ __global__ __launch_bounds__(FIN_THREADS) void rowbn_bwd_finalize_kernel(const f
         tsx += fin_wave_sum(owner ? sx : 0.0);
         if (owner) {
             float *cs = c12 + (size_t)seg * 2 * C;
-            cs[c] = training ? (float)(s / (double)P) : 0.0f;       // eval-mode BN: no batch terms
-            cs[C + c] = training ? (float)(sx / (double)P) : 0.0f;
+            const float c1 = training ? (float)(s / (double)P) : 0.0f;       // eval-mode BN: no batch terms
+            const float c2 = training ? (float)(sx / (double)P) : 0.0f;
+            cs[c] = c1;
+            cs[C + c] = c2;
+            if (cb) {
+                const float mu = mean ? mean[(size_t)seg * C + c] : 0.0f, rs = rstd ? rstd[(size_t)seg * C + c] : 1.0f;
+                const float a = (gamma ? gamma[c] : 1.0f) * rs, f = a * rs * c2;
+                float *o = cb + (size_t)seg * 4 * C + c;
+                o[0] = a; o[C] = f * mu; o[2 * C] = -a * c1; o[3 * C] = f;
+            }
         }
     }
     if (lane != 0) return;
@@ -836,6 +857,48 @@ extern "C" size_t tpg_rowbn_workspace_bytes(int C, int nseg) {
     return sizeof(float) * (WS_HEAD + (size_t)nseg * ((size_t)BN_MAX_BLOCKS * 2 * C + 2 * (size_t)C));
 }
 
+namespace {
+// the two launches of the batch statistics (P = rows per segment); ci_out: see rowbn_stats_finalize_kernel
+void launch_stats(const void *x, int dtype_in, long long P, int C, float eps, float momentum, float *running_mean,
+                  float *running_var, long long *num_batches_tracked, const float *mean_shift, float *mean, float *rstd,
+                  float *wsf, int nseg, const float *gamma, const float *beta, float *ci_out, hipStream_t st) {
+    // statistics use the INPUT type's vector width
+    const int ne = dtype_in == TPG_DTYPE_BF16 ? 8 : 4;
+    const int rpi = BN_THREADS / (C / ne);
+    const int G = seg_blocks(stats_blocks(P, rpi), nseg);
+    const dim3 fg((C + FIN_CH - 1) / FIN_CH);
+    if (dtype_in == TPG_DTYPE_BF16) {
+        const __hip_bfloat16 *xx = static_cast<const __hip_bfloat16 *>(x);
+        hipLaunchKernelGGL(rowbn_stats_kernel<__hip_bfloat16>, dim3(G, nseg), dim3(BN_THREADS), 0, st, xx, P, C, wsf);
+        hipLaunchKernelGGL(rowbn_stats_finalize_kernel<__hip_bfloat16>, fg, dim3(FIN_THREADS), 0, st, xx, wsf, G, P,
+                           C, eps, momentum, running_mean, running_var, num_batches_tracked, mean_shift, mean, rstd, nseg,
+                           gamma, beta, ci_out);
+    } else {
+        const float *xx = static_cast<const float *>(x);
+        hipLaunchKernelGGL(rowbn_stats_kernel<float>, dim3(G, nseg), dim3(BN_THREADS), 0, st, xx, P, C, wsf);
+        hipLaunchKernelGGL(rowbn_stats_finalize_kernel<float>, fg, dim3(FIN_THREADS), 0, st, xx, wsf, G, P, C, eps,
+                           momentum, running_mean, running_var, num_batches_tracked, mean_shift, mean, rstd, nseg, gamma,
+                           beta, ci_out);
+    }
+}
+}  // namespace
+
+// Training-mode batch statistics of x alone (phase STATS of tpg_rowbn_fwd) and, from the same finalize launch, the
+// folded constants ci (nseg,4,C) = sc | sh | mu | rs that tpg_mlp_consts would make of them.
+extern "C" int tpg_rowbn_stats_consts(const void *x, int dtype_in, long long P, int C, float eps, float momentum,
+                                      float *running_mean, float *running_var, long long *num_batches_tracked,
+                                      const float *mean_shift, const float *gamma, const float *beta, float *mean,
+                                      float *rstd, float *ci, void *ws, int nseg, void *stream) {
+    if (P <= 0 || C <= 0 || nseg < 1 || nseg > 65535 || P % nseg) return TPG_ERR_ARG;
+    if (!x || !ws || !mean || !rstd || !ci) return TPG_ERR_ARG;
+    if (!bn_dtype_ok(dtype_in) || !bn_shape_ok(dtype_in, dtype_in, C)) return TPG_ERR_UNSUPPORTED;
+    if ((reinterpret_cast<uintptr_t>(x) | reinterpret_cast<uintptr_t>(ws)) & 15) return TPG_ERR_UNSUPPORTED;
+    launch_stats(x, dtype_in, P / nseg, C, eps, momentum, running_mean, running_var, num_batches_tracked, mean_shift, mean,
+                 rstd, static_cast<float *>(ws), nseg, gamma, beta, ci, tpg_stream(stream));
+    TPG_RETURN_IF_LAUNCH_FAILED();
+    return TPG_OK;
+}
+
 extern "C" int tpg_rowbn_fwd(const void *x, int dtype_in, long long P, int K, int C, float eps, float momentum,
                              int training, float *running_mean, float *running_var,
                              long long *num_batches_tracked, const float *mean_shift, const float *gamma,
@@ -853,24 +916,10 @@ extern "C" int tpg_rowbn_fwd(const void *x, int dtype_in, long long P, int K, in
         return TPG_ERR_UNSUPPORTED;
     hipStream_t st = tpg_stream(stream);
     float *wsf = static_cast<float *>(ws);
-    if (training && phase != TPG_BN_PHASE_APPLY) {
-        // statistics use the INPUT type's vector width
-        const int ne = dtype_in == TPG_DTYPE_BF16 ? 8 : 4;
-        const int rpi = BN_THREADS / (C / ne);
-        const int G = seg_blocks(stats_blocks(P, rpi), nseg);
-        const dim3 fg((C + FIN_CH - 1) / FIN_CH);
-        if (dtype_in == TPG_DTYPE_BF16) {
-            const __hip_bfloat16 *xx = static_cast<const __hip_bfloat16 *>(x);
-            hipLaunchKernelGGL(rowbn_stats_kernel<__hip_bfloat16>, dim3(G, nseg), dim3(BN_THREADS), 0, st, xx, P, C, wsf);
-            hipLaunchKernelGGL(rowbn_stats_finalize_kernel<__hip_bfloat16>, fg, dim3(FIN_THREADS), 0, st, xx, wsf, G, P,
-                               C, eps, momentum, running_mean, running_var, num_batches_tracked, mean_shift, mean, rstd, nseg);
-        } else {
-            const float *xx = static_cast<const float *>(x);
-            hipLaunchKernelGGL(rowbn_stats_kernel<float>, dim3(G, nseg), dim3(BN_THREADS), 0, st, xx, P, C, wsf);
-            hipLaunchKernelGGL(rowbn_stats_finalize_kernel<float>, fg, dim3(FIN_THREADS), 0, st, xx, wsf, G, P, C, eps,
-                               momentum, running_mean, running_var, num_batches_tracked, mean_shift, mean, rstd, nseg);
-        }
-    }  // eval mode: the caller has filled mean / rstd from the running statistics
+    if (training && phase != TPG_BN_PHASE_APPLY)
+        launch_stats(x, dtype_in, P, C, eps, momentum, running_mean, running_var, num_batches_tracked, mean_shift, mean,
+                     rstd, wsf, nseg, nullptr, nullptr, nullptr, st);
+    // eval mode: the caller has filled mean / rstd from the running statistics
     if (phase == TPG_BN_PHASE_STATS) {
         TPG_RETURN_IF_LAUNCH_FAILED();
         return TPG_OK;
@@ -921,11 +970,14 @@ extern "C" int tpg_rowbn_fwd(const void *x, int dtype_in, long long P, int K, in
     return TPG_OK;
 }
 
-extern "C" int tpg_rowbn_bwd(const void *gy, int dtype_g, const void *x, int dtype_in, const uint8_t *argmax,
-                             const void *y, int dtype_y, long long P, int K, int C, int training,
-                             const float *mean, const float *rstd, const float *gamma, const float *beta,
-                             float slope, float *dgamma, float *dbeta, void *dx, void *ws, int nseg, int phase,
-                             void *stream) {
+namespace {
+// tpg_rowbn_bwd; c12_out: where the finalize launch writes c12 (NULL: inside ws, where the apply phase reads it),
+// cb_out: see rowbn_bwd_finalize_kernel
+int rowbn_bwd_impl(const void *gy, int dtype_g, const void *x, int dtype_in, const uint8_t *argmax,
+                   const void *y, int dtype_y, long long P, int K, int C, int training,
+                   const float *mean, const float *rstd, const float *gamma, const float *beta,
+                   float slope, float *dgamma, float *dbeta, void *dx, void *ws, int nseg, int phase,
+                   float *c12_out, float *cb_out, void *stream) {
     if (P <= 0 || C <= 0 || K < 0 || K > 256 || nseg < 1 || nseg > 65535 || P % nseg) return TPG_ERR_ARG;
     P /= nseg;                                    // rows per segment from here on
     if (K > 0 && P % K) return TPG_ERR_ARG;
@@ -940,7 +992,7 @@ extern "C" int tpg_rowbn_bwd(const void *gy, int dtype_g, const void *x, int dty
     if (!(K > 0 && y && dtype_y == dtype_g && !(reinterpret_cast<uintptr_t>(y) & 15))) y = nullptr;
     hipStream_t st = tpg_stream(stream);
     float *wsf = static_cast<float *>(ws);
-    float *c12 = wsf + WS_HEAD + (size_t)nseg * BN_MAX_BLOCKS * 2 * C;      // (nseg, 2, C)
+    float *c12 = c12_out ? c12_out : wsf + WS_HEAD + (size_t)nseg * BN_MAX_BLOCKS * 2 * C;      // (nseg, 2, C)
     const int ne = (dtype_in == TPG_DTYPE_BF16 || dtype_g == TPG_DTYPE_BF16) ? 8 : 4;
     const int rpi = BN_THREADS / (C / ne);
     const long long rows_g = K > 0 ? P / K : P;
@@ -973,7 +1025,7 @@ extern "C" int tpg_rowbn_bwd(const void *gy, int dtype_g, const void *x, int dty
                                mean, rstd, gamma, beta, slope, wsf);                                        \
         if (need_reduce)                                                                                    \
             hipLaunchKernelGGL(rowbn_bwd_finalize_kernel, dim3((C + FIN_CH - 1) / FIN_CH), dim3(FIN_THREADS), 0, st, \
-                               wsf, G, P, C, training, dgamma, dbeta, c12, nseg);                           \
+                               wsf, G, P, C, training, dgamma, dbeta, c12, nseg, mean, rstd, gamma, cb_out); \
         if (!do_apply) {                                                                                    \
         } else if (K > 0) {                                                                                 \
             if (gu == 4) TPG_BN_BWD_APPLY_MAX(TI, TG, 4);                                                   \
@@ -992,6 +1044,16 @@ extern "C" int tpg_rowbn_bwd(const void *gy, int dtype_g, const void *x, int dty
     TPG_RETURN_IF_LAUNCH_FAILED();
     return TPG_OK;
 }
+}  // namespace
+
+extern "C" int tpg_rowbn_bwd(const void *gy, int dtype_g, const void *x, int dtype_in, const uint8_t *argmax,
+                             const void *y, int dtype_y, long long P, int K, int C, int training,
+                             const float *mean, const float *rstd, const float *gamma, const float *beta,
+                             float slope, float *dgamma, float *dbeta, void *dx, void *ws, int nseg, int phase,
+                             void *stream) {
+    return rowbn_bwd_impl(gy, dtype_g, x, dtype_in, argmax, y, dtype_y, P, K, C, training, mean, rstd, gamma, beta, slope,
+                          dgamma, dbeta, dx, ws, nseg, phase, nullptr, nullptr, stream);
+}
 
 // The reduction half of tpg_rowbn_bwd alone, with its per-channel results handed to the caller:
 // c12 (nseg,2,C) = (sum gg / P | sum gg*xhat / P) per segment, dgamma / dbeta (C, may be NULL).  The
@@ -1004,12 +1066,19 @@ extern "C" int tpg_rowbn_bwd_sums(const void *gy, int dtype_g, const void *x, in
                                   void *stream) {
     if (!c12 || nseg < 1) return TPG_ERR_ARG;
     // (dx is not written in the statistics phase; any non-null pointer passes the argument check)
-    const int rc = tpg_rowbn_bwd(gy, dtype_g, x, dtype_in, argmax, y, dtype_y, P, K, C, training, mean, rstd, gamma,
-                                 beta, slope, dgamma, dbeta, const_cast<void *>(x), ws, nseg, TPG_BN_PHASE_STATS, stream);
-    if (rc) return rc;
-    const float *src = static_cast<const float *>(ws) + WS_HEAD + (size_t)nseg * BN_MAX_BLOCKS * 2 * C;
-    if (hipMemcpyAsync(c12, src, sizeof(float) * (size_t)nseg * 2 * C, hipMemcpyDeviceToDevice, tpg_stream(stream)) !=
-        hipSuccess)
-        return TPG_ERR_LAUNCH;
-    return TPG_OK;
+    // the finalize launch writes c12 where the caller wants it (it used to land in ws and be copied out)
+    return rowbn_bwd_impl(gy, dtype_g, x, dtype_in, argmax, y, dtype_y, P, K, C, training, mean, rstd, gamma, beta, slope,
+                          dgamma, dbeta, const_cast<void *>(x), ws, nseg, TPG_BN_PHASE_STATS, c12, nullptr, stream);
+}
+
+// The same, and from the same finalize launch cb (nseg,4,C) = a | f*mu | e | f: what tpg_mlp_consts(..., c12, cb)
+// would fold from mean, rstd, gamma and c12 for the fused tail's gradient kernels.
+extern "C" int tpg_rowbn_bwd_sums_consts(const void *gy, int dtype_g, const void *x, int dtype_in, const uint8_t *argmax,
+                                         const void *y, int dtype_y, long long P, int K, int C, int training,
+                                         const float *mean, const float *rstd, const float *gamma, const float *beta,
+                                         float slope, float *dgamma, float *dbeta, float *c12, float *cb, void *ws,
+                                         int nseg, void *stream) {
+    if (!c12 || !cb || nseg < 1) return TPG_ERR_ARG;
+    return rowbn_bwd_impl(gy, dtype_g, x, dtype_in, argmax, y, dtype_y, P, K, C, training, mean, rstd, gamma, beta, slope,
+                          dgamma, dbeta, const_cast<void *>(x), ws, nseg, TPG_BN_PHASE_STATS, c12, cb, stream);
 }

@@ -424,32 +424,45 @@ class HipBackend:
         return ws
 
     def mlp_fwd(self, x, ss_in, slope_in, W, nseg, eps=0.0, momentum=0.0, running_mean=None, running_var=None,
-                num_batches_tracked=None, mean_shift=None, gamma_out=None, beta_out=None, stats=True):
+                num_batches_tracked=None, mean_shift=None, gamma_out=None, beta_out=None, stats=True, mean_rstd=False):
         """y = W . lrelu(sc * x + sh) on bf16 rows [+ batch statistics of y].
         ss_in: None (identity) or a tensor whose per-segment blocks START with sc | sh of the input
         BatchNorm -- (nseg,2,Cin) or a ci block (nseg,4,Cin).
-        -> y (P,Cout) bf16, ci_out (nseg,4,Cout) = sc | sh | mu | rs of the OUTPUT BatchNorm (None if not stats)."""
+        -> y (P,Cout) bf16, ci_out (nseg,4,Cout) = sc | sh | mu | rs of the OUTPUT BatchNorm (None if not stats)
+        [, mean, rstd (nseg,Cout) as tensors of their own (mean_rstd: the finalize launch writes them anyway)]."""
         P, Cin = x.shape
         w_per_seg = int(W.dim() == 3 and W.shape[0] == nseg and nseg > 1)
         Cout = W.shape[-2]
         y = torch.empty((P, Cout), dtype=torch.bfloat16, device=x.device)
         ci_out = torch.empty((nseg, 4, Cout), dtype=torch.float32, device=x.device) if stats else None
         ws = self._mlp_ws(x, max(Cin, Cout), nseg)
+        mr = torch.empty((2, nseg, Cout), dtype=torch.float32, device=x.device) if (stats and mean_rstd) else None
         ss_stride = 0 if ss_in is None else ss_in.shape[1] * ss_in.shape[2]
         self._call("tpg_mlp_fwd", "mlp_fwd", 2 * P * (Cin + Cout), x,
                    _ptr(x), P, Cin, Cout, nseg, _ptr(ss_in), ss_stride, float(slope_in), _ptr(W), w_per_seg, _ptr(y),
                    float(eps), float(momentum), _ptr(running_mean), _ptr(running_var), _ptr(num_batches_tracked),
-                   _ptr(mean_shift), _ptr(gamma_out), _ptr(beta_out), None, None, _ptr(ci_out), _ptr(ws),
-                   flops=2 * P * Cin * Cout)
+                   _ptr(mean_shift), _ptr(gamma_out), _ptr(beta_out), _ptr(None if mr is None else mr[0]),
+                   _ptr(None if mr is None else mr[1]), _ptr(ci_out), _ptr(ws), flops=2 * P * Cin * Cout)
+        if mr is not None:
+            return y, ci_out, mr[0], mr[1]
         return y, ci_out
 
-    def rowbn_stats(self, x, eps, momentum, running_mean, running_var, num_batches_tracked, nseg, mean_shift):
+    def rowbn_stats(self, x, eps, momentum, running_mean, running_var, num_batches_tracked, nseg, mean_shift,
+                    consts=None):
         """Training-mode batch statistics of x (P,C) alone (the reduction half of rowbn_fwd): mean, rstd
-        (nseg,C); running statistics / batch counter updated like nn.BatchNorm's forward."""
+        (nseg,C); running statistics / batch counter updated like nn.BatchNorm's forward.
+        consts = (gamma, beta): also ci (nseg,4,C) = sc | sh | mu | rs from the same finalize launch -> (mean, rstd, ci)."""
         P, Cc = x.shape
         mean = torch.empty((nseg, Cc), dtype=torch.float32, device=x.device)
         rstd = torch.empty((nseg, Cc), dtype=torch.float32, device=x.device)
         ws = self._bn_ws(x, Cc, nseg)
+        if consts is not None:
+            ci = torch.empty((nseg, 4, Cc), dtype=torch.float32, device=x.device)
+            self._call("tpg_rowbn_stats_consts", "rowbn_fwd_stats", x.element_size() * P * Cc, x,
+                       _ptr(x), _DTYPE_CODE[x.dtype], P, Cc, float(eps), float(momentum), _ptr(running_mean),
+                       _ptr(running_var), _ptr(num_batches_tracked), _ptr(mean_shift), _ptr(consts[0]), _ptr(consts[1]),
+                       _ptr(mean), _ptr(rstd), _ptr(ci), _ptr(ws), int(nseg))
+            return mean, rstd, ci
         self._call("tpg_rowbn_fwd", "rowbn_fwd_stats", x.element_size() * P * Cc, x,
                    _ptr(x), _DTYPE_CODE[x.dtype], P, 0, Cc, float(eps), float(momentum), 1, _ptr(running_mean),
                    _ptr(running_var), _ptr(num_batches_tracked), _ptr(mean_shift), None, None, 1.0, _ptr(mean),
@@ -469,9 +482,9 @@ class HipBackend:
                    float(slope), _ptr(mean), _ptr(rstd), _ptr(y), _DTYPE_CODE[out_dtype], _ptr(arg), _ptr(ws), int(nseg), 2)
         return y, arg
 
-    def rowbn_bwd_sums(self, gy, x, arg, y, K, mean, rstd, gamma, beta, slope, need_affine, nseg):
+    def rowbn_bwd_sums(self, gy, x, arg, y, K, mean, rstd, gamma, beta, slope, need_affine, nseg, want_cb=False):
         """Backward sums of a training-mode BatchNorm (+LeakyReLU, + max over K): c12 (nseg,2,C) and, if
-        wanted, dgamma / dbeta."""
+        wanted, dgamma / dbeta [and cb (nseg,4,C) = a | f*mu | e | f from the same finalize launch, appended]."""
         P, Cc = x.shape
         c12 = torch.empty((nseg, 2, Cc), dtype=torch.float32, device=x.device)
         dgamma = torch.empty(Cc, dtype=torch.float32, device=x.device) if need_affine else None
@@ -479,6 +492,13 @@ class HipBackend:
         ws = self._bn_ws(x, Cc, nseg)
         if y is not None and (not K or y.dtype != gy.dtype):
             y = None
+        if want_cb:
+            cb = torch.empty((nseg, 4, Cc), dtype=torch.float32, device=x.device)
+            self._call("tpg_rowbn_bwd_sums_consts", "rowbn_bwd_reduce", 2 * gy.element_size() * gy.numel(), x,
+                       _ptr(gy), _DTYPE_CODE[gy.dtype], _ptr(x), _DTYPE_CODE[x.dtype], _ptr(arg), _ptr(y),
+                       _DTYPE_CODE[y.dtype] if y is not None else 0, P, K, Cc, 1, _ptr(mean), _ptr(rstd), _ptr(gamma),
+                       _ptr(beta), float(slope), _ptr(dgamma), _ptr(dbeta), _ptr(c12), _ptr(cb), _ptr(ws), int(nseg))
+            return c12, dgamma, dbeta, cb
         self._call("tpg_rowbn_bwd_sums", "rowbn_bwd_reduce", 2 * gy.element_size() * gy.numel(), x,
                    _ptr(gy), _DTYPE_CODE[gy.dtype], _ptr(x), _DTYPE_CODE[x.dtype], _ptr(arg), _ptr(y),
                    _DTYPE_CODE[y.dtype] if y is not None else 0, P, K, Cc, 1, _ptr(mean), _ptr(rstd), _ptr(gamma),
@@ -1177,15 +1197,14 @@ class _MlpTail(torch.autograd.Function):
         Ws = [tensors[3 * l + 2] for l in range(L)]
         xs, cis = [x0], []
         rm, rv, nbt = states[0]
-        m0, r0 = be.rowbn_stats(x0, eps[0], moms[0], rm, rv, nbt, nseg, shifts[0])
-        cis.append(be.mlp_consts(m0, r0, gam[0], bet[0], None, True, False)[0])       # sc | sh | mu | rs
+        cis.append(be.rowbn_stats(x0, eps[0], moms[0], rm, rv, nbt, nseg, shifts[0], consts=(gam[0], bet[0]))[2])  # sc | sh | mu | rs
         for l in range(L):
             rm, rv, nbt = states[l + 1]
-            y, ci = be.mlp_fwd(xs[-1], cis[-1], slopes[l], Ws[l], nseg, eps[l + 1], moms[l + 1], rm, rv, nbt,
-                               shifts[l + 1], gam[l + 1], bet[l + 1])
+            y, ci, *mr = be.mlp_fwd(xs[-1], cis[-1], slopes[l], Ws[l], nseg, eps[l + 1], moms[l + 1], rm, rv, nbt,
+                                    shifts[l + 1], gam[l + 1], bet[l + 1], mean_rstd=(l == L - 1))
             xs.append(y)
             cis.append(ci)
-        mean_L, rstd_L = cis[-1][:, 2].contiguous(), cis[-1][:, 3].contiguous()
+        mean_L, rstd_L = mr                          # of the last BatchNorm, written by the same finalize launch
         out, arg = be.rowbn_apply_max(xs[-1], K, mean_L, rstd_L, gam[-1], bet[-1], slopes[L], torch.bfloat16, nseg)
         ctx.save_for_backward(*xs, *cis, *gam, *bet, *Ws, mean_L, rstd_L, out, *([arg] if arg is not None else []))
         ctx.cfg = (nseg, K, slopes, L)
@@ -1211,10 +1230,9 @@ class _MlpTail(torch.autograd.Function):
         grads_aff = [None] * n
         grads_w = [None] * L
         # the last BatchNorm (+ act, + max): its sums come from (gout, out) alone
-        c12, dg, db = be.rowbn_bwd_sums(gout, xs[L], arg, out if K else None, K, mean_L, rstd_L, gam[L], bet[L],
-                                        slopes[L], need_aff[L], nseg)
+        c12, dg, db, cb = be.rowbn_bwd_sums(gout, xs[L], arg, out if K else None, K, mean_L, rstd_L, gam[L], bet[L],
+                                            slopes[L], need_aff[L], nseg, want_cb=True)
         grads_aff[L] = (dg, db)
-        _, cb = be.mlp_consts(mean_L, rstd_L, gam[L], bet[L], c12, False, True)
         # the arriving gradient lives on each group's arg-max row: a * lrelu'(y) * gout per (group, channel)
         g_next, arg_next, K_next = be.mlp_max_prep(gout, out, cb, slopes[L], nseg), arg, K
         for l in range(L, 0, -1):                    # layer l: x_{l-1} -> x_l

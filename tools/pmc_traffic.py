@@ -23,7 +23,7 @@ KERNELS = {  # bench op name -> substring of the kernel symbol
     "mlp_fwd": "mlp_fwd_kernel",
     "mlp_dgrad": "mlp_dgrad_kernel",
     "mlp_wgrad": "mlp_wgrad_kernel",
-    "mlp_bn_bwd_apply": "mlp_bn_bwd_apply_kernel",
+    "mlp_bn_bwd_apply": "mlp_bn_bwd_apply_",          # plain and row-sum form
     "small_tail_fwd": "small_tail_fwd_kernel",
     "small_tail_bwd": "small_tail_bwd_kernel",
     "knn_mfma": "knn_mfma_kernel",
