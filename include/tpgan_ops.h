@@ -222,7 +222,9 @@ int tpg_rowbn_bwd_sums(const void *gy, int dtype_g, const void *x, int dtype_in,
 /* The statistics / sums launches above with the folded per-channel constants of the fused tail (tpg_mlp_consts)
  * written by the SAME finalize launch -- a tail's first and last BatchNorm need no tpg_mlp_consts launch of their own:
  *   tpg_rowbn_stats_consts   : phase STATS of tpg_rowbn_fwd (training mode) + ci (nseg,4,C) = sc | sh | mu | rs
- *   tpg_rowbn_bwd_sums_consts: tpg_rowbn_bwd_sums + cb (nseg,4,C) = a | f*mu | e | f */
+ *   tpg_rowbn_bwd_sums_consts: tpg_rowbn_bwd_sums + cb (nseg,4,C) = a | f*mu | e | f, and (ag non-NULL; K > 0, y given
+ *                              in gy's type, else TPG_ERR_UNSUPPORTED) ag (P/K, C) = tpg_mlp_max_prep's output, written
+ *                              by the reduction from the rows it reads anyway */
 int tpg_rowbn_stats_consts(const void *x, int dtype_in, long long P, int C, float eps, float momentum,
                            float *running_mean, float *running_var, long long *num_batches_tracked,
                            const float *mean_shift, const float *gamma, const float *beta, float *mean, float *rstd,
@@ -230,7 +232,7 @@ int tpg_rowbn_stats_consts(const void *x, int dtype_in, long long P, int C, floa
 int tpg_rowbn_bwd_sums_consts(const void *gy, int dtype_g, const void *x, int dtype_in, const uint8_t *argmax,
                               const void *y, int dtype_y, long long P, int K, int C, int training, const float *mean,
                               const float *rstd, const float *gamma, const float *beta, float slope, float *dgamma,
-                              float *dbeta, float *c12, float *cb, void *ws, int nseg, void *stream);
+                              float *dbeta, float *c12, float *cb, void *ag, void *ws, int nseg, void *stream);
 
 /* ---- fused shared-MLP tail layer on MFMA tiles (csrc/mlp_fused.hip) --------------------------
  * The grouped-feature x MLP-weight contraction of set abstraction / flow embedding

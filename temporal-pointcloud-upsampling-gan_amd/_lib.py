@@ -46,7 +46,7 @@ SIGNATURES = {
     "tpg_spectral_norm_multi_fwd": [_P, _I, _I, _P, _I, _F, _P],
     "tpg_spectral_norm_multi_bwd": [_P, _I, _I, _P, _P, _P, _P, _P],
     "tpg_rowbn_bwd_sums": [_P, _I, _P, _I, _P, _P, _I, _L, _I, _I, _I, _P, _P, _P, _P, _F, _P, _P, _P, _P, _I, _P],
-    "tpg_rowbn_bwd_sums_consts": [_P, _I, _P, _I, _P, _P, _I, _L, _I, _I, _I, _P, _P, _P, _P, _F, _P, _P, _P, _P, _P, _I, _P],
+    "tpg_rowbn_bwd_sums_consts": [_P, _I, _P, _I, _P, _P, _I, _L, _I, _I, _I, _P, _P, _P, _P, _F, _P, _P, _P, _P, _P, _P, _I, _P],
     "tpg_rowbn_stats_consts": [_P, _I, _L, _I, _F, _F, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _I, _P],
     "tpg_mlp_consts": [_P, _P, _P, _P, _P, _I, _I, _P, _P, _P],
     "tpg_mlp_max_prep": [_P, _P, _P, _F, _L, _I, _I, _P, _P],

@@ -623,12 +623,15 @@ __global__ __launch_bounds__(BN_THREADS) void rowbn_bwd_reduce_max_kernel(
     const TG *__restrict__ gy, const TG *__restrict__ y, const TI *__restrict__ x,
     const uint8_t *__restrict__ arg, long long Gp, int K, int C, const float *__restrict__ mean,
     const float *__restrict__ rstd, const float *__restrict__ gamma, const float *__restrict__ beta,
-    float slope, float *__restrict__ ws) {
+    float slope, float *__restrict__ ws, TG *__restrict__ ag) {
+    // ag (nseg*Gp, C), optional (needs y): gamma*rstd * lrelu'(y) * gy per (group, channel) -- the MODE_MAX operand of
+    // the fused tail's gradient kernels (tpg_mlp_max_prep's output, same bits), a by-product of the rows read here
     constexpr int NE = (sizeof(TI) == 2 || sizeof(TG) == 2) ? 8 : 4;
     const int cpr = C / NE, rpi = BN_THREADS / cpr;
     const int tid = threadIdx.x;
     const int chunk = tid % cpr, rsub = tid / cpr, col = chunk * NE;
     gy += (size_t)blockIdx.y * Gp * C;
+    if (ag) ag += (size_t)blockIdx.y * Gp * C;
     if (y) y += (size_t)blockIdx.y * Gp * C;
     x += (size_t)blockIdx.y * Gp * K * C;
     arg += (size_t)blockIdx.y * Gp * C;
@@ -659,6 +662,12 @@ __global__ __launch_bounds__(BN_THREADS) void rowbn_bwd_reduce_max_kernel(
             else cy = cg;
             cg.unpack(g);
             cy.unpack(yy);
+            if (ag != nullptr) {
+                float av[NE];
+#pragma unroll
+                for (int i = 0; i < NE; ++i) av[i] = a[i] * (yy[i] > 0.0f ? g[i] : g[i] * slope);
+                Chunk<TG, NE>::store(ag + r * C + col, av);
+            }
 #pragma unroll
             for (int i = 0; i < NE; ++i) {
                 if (inv[i]) {
@@ -977,7 +986,7 @@ int rowbn_bwd_impl(const void *gy, int dtype_g, const void *x, int dtype_in, con
                    const void *y, int dtype_y, long long P, int K, int C, int training,
                    const float *mean, const float *rstd, const float *gamma, const float *beta,
                    float slope, float *dgamma, float *dbeta, void *dx, void *ws, int nseg, int phase,
-                   float *c12_out, float *cb_out, void *stream) {
+                   float *c12_out, float *cb_out, void *ag_out, void *stream) {
     if (P <= 0 || C <= 0 || K < 0 || K > 256 || nseg < 1 || nseg > 65535 || P % nseg) return TPG_ERR_ARG;
     P /= nseg;                                    // rows per segment from here on
     if (K > 0 && P % K) return TPG_ERR_ARG;
@@ -1019,7 +1028,7 @@ int rowbn_bwd_impl(const void *gy, int dtype_g, const void *x, int dtype_in, con
         } else if (K > 0)                                                                                   \
             hipLaunchKernelGGL((rowbn_bwd_reduce_max_kernel<TI, TG>), dim3(G, nseg), dim3(BN_THREADS), 0, st, gg, \
                                static_cast<const TG *>(y), xx, argmax, rows_g, K, C, mean, rstd, gamma, beta, \
-                               slope, wsf);                                                                 \
+                               slope, wsf, y ? static_cast<TG *>(ag_out) : nullptr);                        \
         else                                                                                                \
             hipLaunchKernelGGL((rowbn_bwd_reduce_kernel<TI, TG>), dim3(G, nseg), dim3(BN_THREADS), 0, st, gg, xx, P, C, \
                                mean, rstd, gamma, beta, slope, wsf);                                        \
@@ -1052,7 +1061,7 @@ extern "C" int tpg_rowbn_bwd(const void *gy, int dtype_g, const void *x, int dty
                              float slope, float *dgamma, float *dbeta, void *dx, void *ws, int nseg, int phase,
                              void *stream) {
     return rowbn_bwd_impl(gy, dtype_g, x, dtype_in, argmax, y, dtype_y, P, K, C, training, mean, rstd, gamma, beta, slope,
-                          dgamma, dbeta, dx, ws, nseg, phase, nullptr, nullptr, stream);
+                          dgamma, dbeta, dx, ws, nseg, phase, nullptr, nullptr, nullptr, stream);
 }
 
 // The reduction half of tpg_rowbn_bwd alone, with its per-channel results handed to the caller:
@@ -1068,17 +1077,21 @@ extern "C" int tpg_rowbn_bwd_sums(const void *gy, int dtype_g, const void *x, in
     // (dx is not written in the statistics phase; any non-null pointer passes the argument check)
     // the finalize launch writes c12 where the caller wants it (it used to land in ws and be copied out)
     return rowbn_bwd_impl(gy, dtype_g, x, dtype_in, argmax, y, dtype_y, P, K, C, training, mean, rstd, gamma, beta, slope,
-                          dgamma, dbeta, const_cast<void *>(x), ws, nseg, TPG_BN_PHASE_STATS, c12, nullptr, stream);
+                          dgamma, dbeta, const_cast<void *>(x), ws, nseg, TPG_BN_PHASE_STATS, c12, nullptr, nullptr, stream);
 }
 
 // The same, and from the same finalize launch cb (nseg,4,C) = a | f*mu | e | f: what tpg_mlp_consts(..., c12, cb)
-// would fold from mean, rstd, gamma and c12 for the fused tail's gradient kernels.
+// would fold from mean, rstd, gamma and c12 for the fused tail's gradient kernels.  ag, optional, K > 0 with y of
+// gy's type: (P/K, C) of gy's type = a * lrelu'(y) * gy, tpg_mlp_max_prep's output from the rows the reduction reads
+// anyway.  Returns TPG_ERR_UNSUPPORTED if ag is asked for and y cannot be used (then call tpg_mlp_max_prep).
 extern "C" int tpg_rowbn_bwd_sums_consts(const void *gy, int dtype_g, const void *x, int dtype_in, const uint8_t *argmax,
                                          const void *y, int dtype_y, long long P, int K, int C, int training,
                                          const float *mean, const float *rstd, const float *gamma, const float *beta,
-                                         float slope, float *dgamma, float *dbeta, float *c12, float *cb, void *ws,
-                                         int nseg, void *stream) {
+                                         float slope, float *dgamma, float *dbeta, float *c12, float *cb, void *ag,
+                                         void *ws, int nseg, void *stream) {
     if (!c12 || !cb || nseg < 1) return TPG_ERR_ARG;
+    if (ag && !(K > 0 && y && dtype_y == dtype_g && training && !((reinterpret_cast<uintptr_t>(y) | reinterpret_cast<uintptr_t>(ag)) & 15)))
+        return TPG_ERR_UNSUPPORTED;
     return rowbn_bwd_impl(gy, dtype_g, x, dtype_in, argmax, y, dtype_y, P, K, C, training, mean, rstd, gamma, beta, slope,
-                          dgamma, dbeta, const_cast<void *>(x), ws, nseg, TPG_BN_PHASE_STATS, c12, cb, stream);
+                          dgamma, dbeta, const_cast<void *>(x), ws, nseg, TPG_BN_PHASE_STATS, c12, cb, ag, stream);
 }

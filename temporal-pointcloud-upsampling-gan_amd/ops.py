@@ -484,7 +484,8 @@ class HipBackend:
 
     def rowbn_bwd_sums(self, gy, x, arg, y, K, mean, rstd, gamma, beta, slope, need_affine, nseg, want_cb=False):
         """Backward sums of a training-mode BatchNorm (+LeakyReLU, + max over K): c12 (nseg,2,C) and, if
-        wanted, dgamma / dbeta [and cb (nseg,4,C) = a | f*mu | e | f from the same finalize launch, appended]."""
+        wanted, dgamma / dbeta [want_cb: and cb (nseg,4,C) = a | f*mu | e | f from the same finalize launch, and ag =
+        mlp_max_prep's output (or None where the reduction cannot make it: no y of gy's type), appended]."""
         P, Cc = x.shape
         c12 = torch.empty((nseg, 2, Cc), dtype=torch.float32, device=x.device)
         dgamma = torch.empty(Cc, dtype=torch.float32, device=x.device) if need_affine else None
@@ -494,11 +495,12 @@ class HipBackend:
             y = None
         if want_cb:
             cb = torch.empty((nseg, 4, Cc), dtype=torch.float32, device=x.device)
-            self._call("tpg_rowbn_bwd_sums_consts", "rowbn_bwd_reduce", 2 * gy.element_size() * gy.numel(), x,
+            ag = torch.empty_like(gy) if (K and y is not None) else None
+            self._call("tpg_rowbn_bwd_sums_consts", "rowbn_bwd_reduce", (3 if ag is not None else 2) * gy.element_size() * gy.numel(), x,
                        _ptr(gy), _DTYPE_CODE[gy.dtype], _ptr(x), _DTYPE_CODE[x.dtype], _ptr(arg), _ptr(y),
                        _DTYPE_CODE[y.dtype] if y is not None else 0, P, K, Cc, 1, _ptr(mean), _ptr(rstd), _ptr(gamma),
-                       _ptr(beta), float(slope), _ptr(dgamma), _ptr(dbeta), _ptr(c12), _ptr(cb), _ptr(ws), int(nseg))
-            return c12, dgamma, dbeta, cb
+                       _ptr(beta), float(slope), _ptr(dgamma), _ptr(dbeta), _ptr(c12), _ptr(cb), _ptr(ag), _ptr(ws), int(nseg))
+            return c12, dgamma, dbeta, cb, ag
         self._call("tpg_rowbn_bwd_sums", "rowbn_bwd_reduce", 2 * gy.element_size() * gy.numel(), x,
                    _ptr(gy), _DTYPE_CODE[gy.dtype], _ptr(x), _DTYPE_CODE[x.dtype], _ptr(arg), _ptr(y),
                    _DTYPE_CODE[y.dtype] if y is not None else 0, P, K, Cc, 1, _ptr(mean), _ptr(rstd), _ptr(gamma),
@@ -1230,11 +1232,12 @@ class _MlpTail(torch.autograd.Function):
         grads_aff = [None] * n
         grads_w = [None] * L
         # the last BatchNorm (+ act, + max): its sums come from (gout, out) alone
-        c12, dg, db, cb = be.rowbn_bwd_sums(gout, xs[L], arg, out if K else None, K, mean_L, rstd_L, gam[L], bet[L],
-                                            slopes[L], need_aff[L], nseg, want_cb=True)
+        c12, dg, db, cb, ag = be.rowbn_bwd_sums(gout, xs[L], arg, out if K else None, K, mean_L, rstd_L, gam[L], bet[L],
+                                                slopes[L], need_aff[L], nseg, want_cb=True)
         grads_aff[L] = (dg, db)
         # the arriving gradient lives on each group's arg-max row: a * lrelu'(y) * gout per (group, channel)
-        g_next, arg_next, K_next = be.mlp_max_prep(gout, out, cb, slopes[L], nseg), arg, K
+        # (normally a by-product of the reduction above)
+        g_next, arg_next, K_next = (ag if ag is not None else be.mlp_max_prep(gout, out, cb, slopes[L], nseg)), arg, K
         for l in range(L, 0, -1):                    # layer l: x_{l-1} -> x_l
             if need_w[l - 1]:
                 grads_w[l - 1] = be.mlp_wgrad(xs[l], g_next, arg_next, K_next, cb, xs[l - 1], cis[l - 1], slopes[l - 1],

@@ -103,3 +103,10 @@ def test_new_entries_reject_bad_arguments_before_any_launch(hip_lib):
     assert hip_lib.tpg_mlp_bn_bwd_apply_rowsum(p, p, p, p, 64, 0, 64, 1, p, p, None) == -1
     assert hip_lib.tpg_mlp_bn_bwd_apply_rowsum(p, p, p, p, 64, 8, 64, 1, p, None, None) == -1
     assert hip_lib.tpg_mlp_bn_bwd_apply_rowsum(p, p, p, p, 64, 8, 60, 1, p, p, None) == -3
+    # statistics / backward sums with the folded constants from the same finalize launch
+    assert hip_lib.tpg_rowbn_stats_consts(p, 1, 64, 64, 1e-5, 0.1, None, None, None, None, p, p, p, p, None, p, 1, None) == -1
+    assert hip_lib.tpg_rowbn_stats_consts(p, 1, 64, 60, 1e-5, 0.1, None, None, None, None, p, p, p, p, p, p, 1, None) == -3
+    assert hip_lib.tpg_rowbn_bwd_sums_consts(p, 1, p, 1, p, p, 1, 64, 8, 64, 1, p, p, p, p, 0.2, None, None, p, None, None,
+                                             p, 1, None) == -1      # no cb
+    assert hip_lib.tpg_rowbn_bwd_sums_consts(p, 1, p, 1, p, None, 1, 64, 8, 64, 1, p, p, p, p, 0.2, None, None, p, p, p,
+                                             p, 1, None) == -3      # ag wanted, no y to take lrelu' from
