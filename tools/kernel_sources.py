@@ -4,7 +4,7 @@ Every aten op that launches a kernel is attributed to the innermost frame inside
 (forward) or to the autograd node that ran it (backward), and counted.  Output: one table,
 sorted by launches per step -- the input for deciding what to fuse next.
 
-    python tools/kernel_sources.py [max_us]      # only kernels shorter than max_us (default 8)
+    python tools/kernel_sources.py [max_us [gonly|full [config]]]      # only kernels shorter than max_us (default 8)
 """
 import collections
 import os
@@ -22,13 +22,14 @@ from tpgan_amd import configs  # noqa: E402
 argv = sys.argv
 max_us = float(argv[1]) if len(argv) > 1 else 8.0
 update_D = not (len(argv) > 2 and argv[2] == "gonly")      # "gonly": the generator-only body (the step's critical chain)
+config = argv[3] if len(argv) > 3 else "cfg2"
 
 torch.backends.cudnn.enabled = False
 dev = torch.device("cuda", 0)
 np.random.seed(0)
-models = configs.build_models("cfg2", dev, capturable=True)
-clips = [configs.make_clip("cfg2", seed=s, device=dev) for s in range(2)]
-step = configs.graphed_step("cfg2", models, clips[0], amp_dtype=torch.bfloat16)
+models = configs.build_models(config, dev, capturable=True)
+clips = [configs.make_clip(config, seed=s, device=dev) for s in range(2)]
+step = configs.graphed_step(config, models, clips[0], amp_dtype=torch.bfloat16)
 step._load(*clips[1])
 step._run_eager(update_D)                                   # the body the graph captured, run eagerly
 torch.cuda.synchronize()
