@@ -267,7 +267,7 @@ class _TallLinearSeg(torch.autograd.Function):
 
 def rows_matmul_seg(x, w):
     """x (nseg*P, Cin) rows in nseg equal blocks, w (nseg, Cout, Cin): block s times w[s]^T."""
-    dtype = torch.get_autocast_gpu_dtype() if (x.is_cuda and torch.is_autocast_enabled()) else x.dtype
+    dtype = torch.get_autocast_dtype('cuda') if (x.is_cuda and torch.is_autocast_enabled()) else x.dtype
     if dtype not in (torch.float32, torch.bfloat16, torch.float16):
         dtype = torch.float32
     with torch.autocast(device_type=x.device.type, enabled=False):
@@ -290,7 +290,7 @@ def rows_matmul(x, w, bias=None):
     lead = x.shape[:-1]
     P = x.numel() // x.shape[-1] if x.numel() else 0
     if P >= TALL_ROWS and x.is_cuda and torch.is_grad_enabled() and w.requires_grad:
-        dtype = torch.get_autocast_gpu_dtype() if torch.is_autocast_enabled() else x.dtype
+        dtype = torch.get_autocast_dtype('cuda') if torch.is_autocast_enabled() else x.dtype
         if dtype in (torch.float32, torch.bfloat16, torch.float16):
             with torch.autocast(device_type="cuda", enabled=False):
                 y = _TallLinear.apply(x.reshape(P, x.shape[-1]), w, bias, dtype)
@@ -314,7 +314,7 @@ def amp_dtype(x):
     """dtype the big grouped tensors should be stored in: the autocast dtype if autocast is
     active for x's device, else x's own dtype."""
     if x.is_cuda and torch.is_autocast_enabled():
-        return torch.get_autocast_gpu_dtype()
+        return torch.get_autocast_dtype('cuda')
     return x.dtype if x.dtype in (torch.float32, torch.bfloat16) else torch.float32
 
 

@@ -131,7 +131,8 @@ def _rel(a, b):
     ((64, 128), 32, 8 * 64 * 32, 1, False), ((64, 128), 32, 2 * 8 * 64 * 32, 2, True),
     ((128, 128), 32, 4096, 1, False), ((128, 256), 16, 3 * 2048, 3, True),
     ((256, 128, 256), 32, 2 * 4096, 2, True), ((256, 256, 256), 32, 4096, 1, False),
-    ((64, 64, 128), 64, 4096, 1, False), ((128, 64), 8, 1000 * 8, 1, False)])
+    ((64, 64, 128), 64, 4096, 1, False), ((128, 64), 8, 1000 * 8, 1, False),
+    ((64, 128), 16, 7 * 320, 7, True), ((64, 128, 128), 16, 70 * 256, 70, True)])     # 70 segments: two sweeps of the finalize kernels
 def test_mlp_tail_forward_backward(chain, K, P, nseg, per_seg_w):
     import tpgan_amd.ops as ops
     torch.manual_seed(sum(chain) + K)

@@ -10,10 +10,11 @@ pytestmark = pytest.mark.gpu
 
 @pytest.mark.parametrize("K", [0, 16, 256])          # 256: few long groups, walked as runs
 @pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
-def test_row_bn_act_segments_equal_separate_calls(K, dtype):
+@pytest.mark.parametrize("nseg,Ps", [(3, 2 * 64 * 16), (7, 512), (70, 256)])   # 7: lane groups of 8 with one idle; 70: two sweeps of the finalize kernels
+def test_row_bn_act_segments_equal_separate_calls(K, dtype, nseg, Ps):
     import tpgan_amd.ops as ops
     torch.manual_seed(0)
-    nseg, Ps, C = 3, 2 * 64 * 16, 64
+    C = 64
     x = (torch.randn(nseg * Ps, C, device="cuda") * 1.5 + torch.arange(nseg, device="cuda").repeat_interleave(Ps)[:, None]).to(dtype)
     gamma = (torch.rand(C, device="cuda") + 0.5).requires_grad_(True)
     beta = (torch.randn(C, device="cuda") * 0.1).requires_grad_(True)
