@@ -501,7 +501,9 @@ class IDGCNLayer(nn.Module):
         # ONE search serves the three neighbour lists built on `low` (gcn.py:253-262 searches three
         # times): the local 9-NN list and the two EdgeConvs' k-NN lists are prefixes of the longest
         kmax = max(9, self.GCN1.dilated_knn_graph.k, self.GCN2.dilated_knn_graph.k)
-        _, idx_all = ops.neighbour_search(low, low, kmax)
+        # (the search and both EdgeConvs work on fp32 rows: ONE upcast of `low` instead of one per use)
+        low_f = low.float()
+        _, idx_all = ops.neighbour_search(low_f, low_f, kmax)
         idx = idx_all[:, :, :9]
         local = ops.row_combine(low, None, idx.to(torch.int32).contiguous(), ops.ROW_GATHER)   # (B,N,9,C/4)
         B, N, k, q = local.shape
@@ -510,8 +512,8 @@ class IDGCNLayer(nn.Module):
             local_max = ops.row_act_max(local.view(B * N * k, q), 1.0, k).view(B, N, q)
         else:
             local_max = local.max(2)[0]
-        out = torch.cat([local_max, self.GCN1.forward_rows(low, knn_idx=idx_all),
-                         self.GCN2.forward_rows(low, knn_idx=idx_all)], dim=-1)
+        out = torch.cat([local_max, self.GCN1.forward_rows(low_f, knn_idx=idx_all),
+                         self.GCN2.forward_rows(low_f, knn_idx=idx_all)], dim=-1)
         out = rows_seq(self.decoder, out)
         if self.use_layernorm:
             out = self.layernorm(out)

@@ -869,7 +869,7 @@ def neighbour_search(p1, p2, K, lengths1=None, lengths2=None, r=None):
     _need(int(K) >= 1, "K must be >= 1")
     _same_device(p1, p2)
     a = p1.detach().float().contiguous()
-    b = p2.detach().float().contiguous()
+    b = a if p2 is p1 else p2.detach().float().contiguous()       # a cloud searched in itself: one cast, not two
     B = a.shape[0]
     l1 = _lengths(lengths1, B, a.shape[1], a.device)
     l2 = _lengths(lengths2, B, b.shape[1], a.device)
