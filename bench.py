@@ -193,6 +193,12 @@ def roofline_leg(models, clips, steps, sync, amp_dtype):
                  **({"TFLOPs": round(v["tflops"], 1)} if v["flops_per_launch"] else {})} for k, v in summ.items()}
     if "fps" in summ:
         table["fps"]["note"] = "npoint-1 dependent rounds per launch; hidden on a side stream in graph mode"
+    for k in table:
+        if k.startswith("gemm_"):
+            # a torch GEMM call in the launch-by-launch body: the events bracket the host's enqueue work as well (plan
+            # lookup, workspace, split-K views), the GPU idle in between -- NOT kernel time
+            table[k]["note"] = ("HIP events around a torch / hipBLASLt call in the eager body include the host's enqueue gap; "
+                                "kernel time of the library GEMMs: mfma.library_gemm (rocprofv3 summary of the replayed step)")
     return line, table
 
 
