@@ -846,6 +846,10 @@ int seg_blocks(int blocks, int nseg) {
     const int b = (blocks + d - 1) / d;
     return b < 1 ? 1 : b;
 }
+// most workgroups PER SEGMENT of a max-variant launch: TPG_BN_GROUP_CAP / min(nseg, TPG_BN_SEG_DIV), twice that for one
+// to three segments (tools/tune_rowbn.py, forward apply + max: one segment 17.9 -> 15.9 us, three 55.4 -> 47.5, six
+// 85.6 -> 89.1 with the doubled budget, hence not there)
+int group_cap(int nseg, int cap_div) { return (nseg <= 3 ? 2 * TPG_BN_GROUP_CAP : TPG_BN_GROUP_CAP) / cap_div; }
 int group_unroll(int K) { return K % 4 == 0 ? 4 : (K % 2 == 0 ? 2 : 1); }
 // Runs per group for the max-variant walks: 1 unless the launch would have fewer than ~64 K
 // threads at work; then the largest power of two that keeps runs of >= 4 rows (a multiple of
@@ -941,7 +945,7 @@ extern "C" int tpg_rowbn_fwd(const void *x, int dtype_in, long long P, int K, in
     // runs' partial maxima live where the statistics' partial sums were (already consumed):
     // (float + byte) per channel and run, BN_MAX_BLOCKS * 2 floats per channel and segment
     const int L = K > 0 ? group_runs(rows_out, K, C / ne, nseg, BN_MAX_BLOCKS * 8 / 5) : 1;
-    const dim3 g(K > 0 ? row_blocks(rows_out * L, rpi_a, 1, TPG_BN_GROUP_CAP / cap_div)
+    const dim3 g(K > 0 ? row_blocks(rows_out * L, rpi_a, 1, group_cap(nseg, cap_div))
                        : row_blocks(P, rpi_a, TPG_BN_APPLY_ROWS, TPG_BN_APPLY_CAP / cap_div), nseg);
     const dim3 blk(BN_THREADS);
     const int gu = group_unroll(K / L);
@@ -1008,7 +1012,7 @@ int rowbn_bwd_impl(const void *gy, int dtype_g, const void *x, int dtype_in, con
     const int G = seg_blocks(K > 0 ? row_blocks(rows_g, rpi, TPG_BN_YRED_ROWS, BN_MAX_BLOCKS) : stats_blocks(rows_g, rpi), nseg);
     const int cap_div = nseg > TPG_BN_SEG_DIV ? TPG_BN_SEG_DIV : nseg;
     const int L = K > 0 ? group_runs(rows_g, K, C / ne, nseg, 0) : 1;
-    const int GA = K > 0 ? row_blocks(rows_g * L, rpi, 1, TPG_BN_GROUP_CAP / cap_div)
+    const int GA = K > 0 ? row_blocks(rows_g * L, rpi, 1, group_cap(nseg, cap_div))
                          : row_blocks(P, rpi, TPG_BN_APPLY_ROWS, TPG_BN_APPLY_CAP / cap_div);
     // no batch statistics and no affine gradients wanted (pure activation [+max]): dx = a * g,
     // nothing to reduce

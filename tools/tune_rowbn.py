@@ -32,11 +32,15 @@ VARIANTS = {
     "acap1024": {"TPG_BN_APPLY_CAP": 1024},
     "bu4": {"TPG_BN_BWD_U": 4},
     "gcap1k": {"TPG_BN_GROUP_CAP": 1024},
+    "gcap256": {"TPG_BN_GROUP_CAP": 256},
 }
+if os.environ.get("TUNE_ROWBN_ONLY"):      # e.g. TUNE_ROWBN_ONLY=base,round1k
+    VARIANTS = {k: v for k, v in VARIANTS.items() if k in os.environ["TUNE_ROWBN_ONLY"].split(",")}
 # (P rows of ALL segments, K, C, nseg): the shared-MLP tails of the discriminators at cfg2 (B=8) as the
 # step launches them -- T frames x {fake, real} batches as segments
 SHAPES = [(262144, 0, 64, 1), (524288, 0, 64, 2), (786432, 0, 64, 3), (1572864, 0, 64, 6),
-          (524288, 32, 128, 2), (1572864, 32, 128, 6), (393216, 0, 128, 6), (393216, 32, 256, 6)]
+          (524288, 32, 128, 2), (1572864, 32, 128, 6), (393216, 0, 128, 6), (393216, 32, 256, 6),
+          (786432, 32, 128, 3), (1572864, 32, 256, 6), (245760, 20, 128, 1), (147456, 12, 256, 1)]
 
 
 def build():
