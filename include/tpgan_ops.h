@@ -90,10 +90,15 @@ int tpg_frnn_grid_f32(const float *p1, const float *p2, const int64_t *len1, con
 int tpg_chamfer_fwd_f32(const float *src, const float *tgt, int B, int N, int M,
                         float *d1, int64_t *i1, float *d2, int64_t *i2,
                         void *stream);
-/* gsrc (B,N,3) / gtgt (B,M,3) are overwritten (zeroed inside). */
+/* Backward of chamferdist's forward (loss.py:125-127,176-181): g1 (B,N), g2 (B,M) = gradients of d1, d2;
+ * gsrc (B,N,3) / gtgt (B,M,3) are overwritten.  No float atomics: each output point sums its own term and the
+ * terms of the points that chose it as nearest neighbour (inverted i1 / i2, ascending point order) -- bitwise
+ * reproducible and bit-identical to the oracle's two loops.  ws: tpg_chamfer_bwd_workspace_bytes(B, N, M) bytes,
+ * 4-byte aligned. */
+size_t tpg_chamfer_bwd_workspace_bytes(int B, int N, int M);
 int tpg_chamfer_bwd_f32(const float *src, const float *tgt, int B, int N, int M,
                         const int64_t *i1, const int64_t *i2, const float *g1,
-                        const float *g2, float *gsrc, float *gtgt, void *stream);
+                        const float *g2, float *gsrc, float *gtgt, void *ws, void *stream);
 
 /* Furthest point sampling.  Replaces pointnet2_utils.furthest_point_sample --
  * discriminator.py:114.  xyz (B,N,3) -> idx (B,m) int32; temp (B,N) scratch. */
@@ -157,9 +162,11 @@ int tpg_rowcombine_fwd(const void *U, const void *QE, const int32_t *idx, int mo
                        void *stream);
 
 /* per-cloud inverted index of idx (B,SK) with values in [0,N): offs (B,N+1), list (B,SK)
- * = flat (s,k) entry ids grouped by destination row (order inside a group unspecified). */
+ * = flat (s,k) entry ids grouped by destination row, ASCENDING inside a group (a stable radix sort:
+ * the gather-reduce backward then sums in a fixed order -- bitwise reproducible gradients).
+ * tmp: B*SK ints of scratch (may be NULL when N <= 256). */
 int tpg_invert_index(const int32_t *idx, int B, int N, int SK, int32_t *offs, int32_t *list,
-                     void *stream);
+                     int32_t *tmp, void *stream);
 
 /* backward of tpg_rowcombine_fwd; atomics-free gather-reduce over the inverted index.
  * gout (B,S,K,C) of dtype_out; gU (B,N,C) and gQE (grad of QE: (B,S,C) for SUB and EDGE,

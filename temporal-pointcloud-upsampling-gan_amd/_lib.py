@@ -24,7 +24,7 @@ SIGNATURES = {
     "tpg_knn_grid_f32": [_P, _P, _P, _P, _I, _I, _I, _I, _P, _P, _P, _P],
     "tpg_frnn_grid_f32": [_P, _P, _P, _P, _I, _I, _I, _I, _F, _P, _P, _P, _P],
     "tpg_chamfer_fwd_f32": [_P, _P, _I, _I, _I, _P, _P, _P, _P, _P],
-    "tpg_chamfer_bwd_f32": [_P, _P, _I, _I, _I, _P, _P, _P, _P, _P, _P, _P],
+    "tpg_chamfer_bwd_f32": [_P, _P, _I, _I, _I, _P, _P, _P, _P, _P, _P, _P, _P],
     "tpg_fps_f32": [_P, _I, _I, _I, _P, _P, _P],
     "tpg_fps_start_f32": [_P, _P, _I, _I, _I, _I, _P, _P, _P],
     "tpg_gather_fwd_f32": [_P, _P, _I, _I, _I, _I, _P, _P],
@@ -36,7 +36,7 @@ SIGNATURES = {
     "tpg_three_interp_fwd_f32": [_P, _P, _P, _I, _I, _I, _I, _P, _P],
     "tpg_three_interp_bwd_f32": [_P, _P, _P, _I, _I, _I, _I, _P, _P],
     "tpg_rowcombine_fwd": [_P, _P, _P, _I, _I, _I, _I, _I, _I, _I, _I, _F, _P, _P],
-    "tpg_invert_index": [_P, _I, _I, _I, _P, _P, _P],
+    "tpg_invert_index": [_P, _I, _I, _I, _P, _P, _P, _P],
     "tpg_rowcombine_bwd": [_P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _I, _I, _F, _P, _P, _P],
     "tpg_rowbn_fwd": [_P, _I, _L, _I, _I, _F, _F, _I, _P, _P, _P, _P, _P, _P, _F, _P, _P, _P, _I, _P, _P, _I, _I, _P],
     "tpg_rowbn_bwd": [_P, _I, _P, _I, _P, _P, _I, _L, _I, _I, _I, _P, _P, _P, _P, _F, _P, _P, _P, _P, _I, _I, _P],
@@ -60,7 +60,8 @@ SIGNATURES = {
 }
 SIZE_GETTERS = ("tpg_rowbn_workspace_bytes", "tpg_mlp_workspace_bytes")
 OTHER_GETTERS = ("tpg_spectral_norm_multi_stride", "tpg_spectral_norm_multi_bwd_scratch",
-                 "tpg_mlp_wgrad_workspace_bytes", "tpg_frnn_grid_workspace_bytes", "tpg_small_tail_workspace_bytes")
+                 "tpg_mlp_wgrad_workspace_bytes", "tpg_frnn_grid_workspace_bytes", "tpg_small_tail_workspace_bytes",
+                 "tpg_chamfer_bwd_workspace_bytes")
 STRING_GETTERS = ("tpg_version", "tpg_target_arch")
 
 STATUS = {0: "TPG_OK", -1: "TPG_ERR_ARG", -2: "TPG_ERR_LAUNCH", -3: "TPG_ERR_UNSUPPORTED"}
@@ -101,6 +102,8 @@ def load():
     lib.tpg_small_tail_workspace_bytes.restype = C.c_size_t
     lib.tpg_frnn_grid_workspace_bytes.argtypes = [C.c_int, C.c_int]
     lib.tpg_frnn_grid_workspace_bytes.restype = C.c_size_t
+    lib.tpg_chamfer_bwd_workspace_bytes.argtypes = [C.c_int, C.c_int, C.c_int]
+    lib.tpg_chamfer_bwd_workspace_bytes.restype = C.c_size_t
     _lib = lib
     return lib
 

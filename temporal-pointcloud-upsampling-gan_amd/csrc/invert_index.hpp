@@ -1,0 +1,250 @@
+// Per-cloud inverted index with every destination's list in ASCENDING ENTRY ORDER (round 3).
+//
+//   idx (B,SK) values in [0,N)  ->  offs (B,N+1), list (B,SK): list[offs[n] .. offs[n+1]) = the flat
+//   entry ids e with idx[e] == n, ascending.
+//
+// The scatter-add gradients of the path (row gather backward: gcn_lib/pointnet/gcn.py:207-210,
+// discriminator.py:141-145,270-280; Chamfer's target -> source term: loss.py:125-127) are computed as
+// gather-reduces over these lists, so the ORDER inside a list is the order of a float sum.  Round 2 filled
+// the lists through LDS atomics (same lists, arrival order): sums differed at rounding level from run to
+// run and box to box, and the untrained adversarial step amplifies 1e-8 to 1e-3.
+// This form is a stable LSD radix sort of the entries by destination -- no ordering atomics anywhere -- so a
+// training step is bitwise reproducible.
+//
+// One workgroup (16 waves) per cloud.  Wave w owns the w-th contiguous sixteenth of the entries; a pass
+// sorts by one digit (<= 8 bits) of the destination:
+//   histogram  per (digit, wave) counters in LDS (integer atomics: counts do not depend on arrival order);
+//   scan       exclusive, digit-major / wave-minor  -> every wave's first slot per digit;
+//   scatter    a wave walks its entries in order, 64 at a time: the lanes holding the same digit find each
+//              other with one ballot per digit bit, rank = popcount of the lower lanes of that mask, the
+//              group's last lane advances the wave's cursor.  Stable by construction.
+// Two passes for N <= 65536 (three beyond).  The first pass reads idx coalesced (entry id = position) and
+// writes (remaining key bits, entry id) packed into one word when they fit 32 bits (else the later pass
+// gathers idx[e] again); the histogram of pass p+1 is counted while pass p scatters (the wave that will own
+// a slot is slot / chunk).  offs comes from per-destination counters in LDS filled by the first sweep
+// (N <= 32704; beyond -- inference-size clouds, no backward on the path -- from the sorted list itself).
+#pragma once
+#include "tpg_common.hpp"
+
+namespace tpg_inv {
+
+constexpr int kWaves = 16;
+constexpr int kThreads = kWaves * 64;
+constexpr int kMaxBins = 256;
+constexpr int kHist = kMaxBins * kWaves;          // ints per histogram
+constexpr int kUnroll = 8;                        // 64-entry steps whose loads are in flight together
+constexpr int kMaxLdsBytes = 160 * 1024;
+constexpr int kFixedInts = 2 * kHist + 64;        // two histograms + scan slots
+constexpr int kMaxCntRows = kMaxLdsBytes / 4 - kFixedInts;
+
+struct Plan {
+    int bits, passes, ebits, pack, use_cnt;
+    size_t smem;
+};
+
+inline int ceil_log2(long long v) {
+    int b = 0;
+    while ((1LL << b) < v) ++b;
+    return b;
+}
+
+inline Plan plan(int N, int SK) {
+    Plan p;
+    const int total = ceil_log2(N) < 1 ? 1 : ceil_log2(N);
+    p.passes = (total + 7) / 8;
+    p.bits = (total + p.passes - 1) / p.passes;
+    p.ebits = ceil_log2(SK) < 1 ? 1 : ceil_log2(SK);
+    p.pack = (total - p.bits) + p.ebits <= 32 ? 1 : 0;
+    p.use_cnt = N <= kMaxCntRows ? 1 : 0;
+    p.smem = sizeof(int) * ((size_t)kFixedInts + (p.use_cnt ? (size_t)N : 0));
+    return p;
+}
+
+// exclusive scan of a[0..L) in place (L a power of two >= 32 or any L <= 1024 * per), all 1024 threads
+__device__ __forceinline__ void block_exclusive_scan(volatile int *a, int L, volatile int *wsum, int tid) {
+    const int lane = tid & 63, wave = tid >> 6;
+    const int per = (L + kThreads - 1) / kThreads;
+    const int lo = min(tid * per, L), hi = min(lo + per, L);
+    int local = 0;
+    for (int i = lo; i < hi; ++i) local += a[i];
+    int incl = local;
+#pragma unroll
+    for (int d = 1; d < 64; d <<= 1) {
+        const int o = __shfl_up(incl, d);
+        if (lane >= d) incl += o;
+    }
+    if (lane == 63) wsum[wave] = incl;
+    __syncthreads();
+    if (wave == 0) {
+        int w = lane < kWaves ? wsum[lane] : 0;
+#pragma unroll
+        for (int d = 1; d < kWaves; d <<= 1) {
+            const int o = __shfl_up(w, d);
+            if (lane >= d) w += o;
+        }
+        if (lane < kWaves) wsum[kWaves + lane] = w;      // inclusive prefix of the wave sums
+    }
+    __syncthreads();
+    int run = incl - local + (wave ? wsum[kWaves + wave - 1] : 0);
+    for (int i = lo; i < hi; ++i) {
+        const int c = a[i];
+        a[i] = run;
+        run += c;
+    }
+    __syncthreads();
+}
+
+// destination of entry e, clamped like the consumers clamp it (int32: tpg_clamp_idx, as tpg_rowcombine_fwd
+// reads it; int64: the Chamfer nearest-neighbour indices, clamped into [0, N))
+__device__ __forceinline__ int dest_of(const int32_t *id, int e, int N) { return tpg_clamp_idx(id[e], N); }
+__device__ __forceinline__ int dest_of(const int64_t *id, int e, int N) {
+    const long long v = (long long)id[e];
+    return (int)(v < 0 ? 0 : (v >= N ? N - 1 : v));
+}
+
+template <typename IdxT>
+__global__ __launch_bounds__(kThreads) void invert_index_kernel(const IdxT *__restrict__ idx, int N, int SK, int bits,
+                                                                int passes, int ebits, int pack, int use_cnt,
+                                                                int32_t *__restrict__ offs, int32_t *__restrict__ list,
+                                                                int32_t *__restrict__ tmp) {
+    extern __shared__ __attribute__((aligned(16))) int inv_smem[];
+    volatile int *hist0 = inv_smem;                 // two histograms, used in turn by the passes
+    volatile int *wsum = inv_smem + 2 * kHist;
+    int *cnt = inv_smem + kFixedInts;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int b = blockIdx.x;
+    const IdxT *id = idx + (size_t)b * SK;
+    int32_t *of = offs + (size_t)b * (N + 1);
+    int32_t *ls = list + (size_t)b * SK;
+    int32_t *tp = tmp ? tmp + (size_t)b * SK : nullptr;
+    if (SK == 0) {
+        for (int n = tid; n <= N; n += kThreads) of[n] = 0;
+        return;
+    }
+    const int nb = 1 << bits, dmask = nb - 1;
+    const int L = nb * kWaves;
+    const int chunk = (((SK + kWaves - 1) / kWaves) + 63) & ~63;      // entries per wave, whole 64-entry steps
+    const int e_lo = min(wave * chunk, SK), e_hi = min(e_lo + chunk, SK);
+    const unsigned emask = ebits >= 32 ? 0xffffffffu : ((1u << ebits) - 1u);
+    const tpg_u64 lt = lane ? (~0ULL >> (64 - lane)) : 0ULL;          // the lanes below this one
+
+    // ---- sweep A: histogram of the first digit (+ per-destination counts for offs)
+    for (int i = tid; i < L; i += kThreads) hist0[i] = 0;
+    if (use_cnt)
+        for (int n = tid; n < N; n += kThreads) cnt[n] = 0;
+    __syncthreads();
+    for (int base = e_lo; base < e_hi; base += 64 * kUnroll) {
+        int d[kUnroll];
+#pragma unroll
+        for (int u = 0; u < kUnroll; ++u) {
+            const int i = base + u * 64 + lane;
+            d[u] = i < e_hi ? dest_of(id, i, N) : -1;
+        }
+#pragma unroll
+        for (int u = 0; u < kUnroll; ++u)
+            if (d[u] >= 0) {
+                atomicAdd((int *)&hist0[(d[u] & dmask) * kWaves + wave], 1);
+                if (use_cnt) atomicAdd(&cnt[d[u]], 1);
+            }
+    }
+    __syncthreads();
+    if (use_cnt) {
+        // offs = exclusive scan of the counts (left in cnt by the scan, written out coalesced)
+        block_exclusive_scan(cnt, N, wsum, tid);
+        for (int n = tid; n < N; n += kThreads) of[n] = cnt[n];
+        if (tid == 0) of[N] = SK;
+    }
+
+    // ---- the passes.  kh = destination >> bits: the key bits the passes after the first still need
+    for (int p = 0; p < passes; ++p) {
+        volatile int *cur = hist0 + (p & 1) * kHist, *nxt = hist0 + ((p + 1) & 1) * kHist;
+        const bool last = p + 1 == passes;
+        const int32_t *src = p == 0 ? nullptr : (((passes - p) & 1) ? tp : ls);      // what pass p-1 wrote
+        int32_t *dst = ((passes - 1 - p) & 1) ? tp : ls;
+        const bool packed_in = src != nullptr && pack;
+        block_exclusive_scan(cur, L, wsum, tid);
+        if (!last) {
+            for (int i = tid; i < L; i += kThreads) nxt[i] = 0;
+            __syncthreads();
+        }
+        const int dshift = p ? (p - 1) * bits : 0;       // of kh, for this pass's digit (p > 0)
+        for (int base = e_lo; base < e_hi; base += 64 * kUnroll) {
+            int raw[kUnroll], ev[kUnroll], dg[kUnroll], kh[kUnroll];
+#pragma unroll
+            for (int u = 0; u < kUnroll; ++u) {
+                const int i = base + u * 64 + lane;
+                raw[u] = i < e_hi ? (src ? src[i] : i) : 0;
+            }
+#pragma unroll
+            for (int u = 0; u < kUnroll; ++u) {
+                const bool ok = base + u * 64 + lane < e_hi;
+                if (packed_in) {
+                    ev[u] = (int)((unsigned)raw[u] & emask);
+                    kh[u] = (int)((unsigned)raw[u] >> ebits);
+                    dg[u] = (kh[u] >> dshift) & dmask;
+                } else {
+                    ev[u] = raw[u];
+                    const int dest = ok ? dest_of(id, ev[u], N) : 0;
+                    kh[u] = dest >> bits;
+                    dg[u] = p == 0 ? (dest & dmask) : ((kh[u] >> dshift) & dmask);
+                }
+            }
+#pragma unroll
+            for (int u = 0; u < kUnroll; ++u) {
+                if (base + u * 64 >= e_hi) break;                        // wave-uniform
+                const bool valid = base + u * 64 + lane < e_hi;
+                const int digit = dg[u];
+                tpg_u64 m = __ballot(valid);                             // -> the valid lanes with my digit
+                for (int bt = 0; bt < bits; ++bt) {
+                    const bool on = (digit >> bt) & 1;
+                    const tpg_u64 bb = __ballot(valid && on);
+                    m &= on ? bb : ~bb;
+                }
+                if (valid) {
+                    const int rank = __popcll(m & lt), group = __popcll(m);
+                    const int slot = digit * kWaves + wave;
+                    const int pos = cur[slot] + rank;                    // (every lane of the group reads ...
+                    if (last) {
+                        dst[pos] = ev[u];
+                    } else {
+                        dst[pos] = pack ? (int)(((unsigned)kh[u] << ebits) | (unsigned)ev[u]) : ev[u];
+                        const int nd = (kh[u] >> (p * bits)) & dmask;    // digit of pass p + 1
+                        atomicAdd((int *)&nxt[nd * kWaves + pos / chunk], 1);
+                    }
+                    if (rank == group - 1) cur[slot] = pos + 1;          //  ... before its last lane advances the cursor)
+                }
+            }
+        }
+        __syncthreads();            // dst complete and visible to the whole workgroup
+    }
+
+    if (!use_cnt) {
+        // offs from the sorted list: position q opens the lists of every destination in (key[q-1], key[q]]
+        for (int q = tid; q < SK; q += kThreads) {
+            const int k = dest_of(id, ls[q], N);
+            const int kp = q ? dest_of(id, ls[q - 1], N) : -1;
+            for (int n = kp + 1; n <= k; ++n) of[n] = q;
+            if (q == SK - 1)
+                for (int n = k + 1; n <= N; ++n) of[n] = SK;
+        }
+    }
+}
+
+// tmp: B*SK ints of scratch (may be NULL when N <= 256: one pass)
+template <typename IdxT>
+inline int launch(const IdxT *idx, int B, int N, int SK, int32_t *offs, int32_t *list, int32_t *tmp, hipStream_t st) {
+    const Plan p = plan(N, SK);
+    if (p.passes > 1 && !tmp) return TPG_ERR_ARG;
+    static bool raised = false;                 // (idempotent; a race would only set it twice)
+    if (!raised) {
+        if (hipFuncSetAttribute(reinterpret_cast<const void *>(invert_index_kernel<IdxT>),
+                                hipFuncAttributeMaxDynamicSharedMemorySize, kMaxLdsBytes) != hipSuccess)
+            return TPG_ERR_UNSUPPORTED;
+        raised = true;
+    }
+    hipLaunchKernelGGL((invert_index_kernel<IdxT>), dim3(B), dim3(kThreads), p.smem, st, idx, N, SK, p.bits, p.passes,
+                       p.ebits, p.pack, p.use_cnt, offs, list, tmp);
+    return TPG_OK;
+}
+
+}  // namespace tpg_inv

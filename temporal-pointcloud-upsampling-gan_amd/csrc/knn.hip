@@ -26,6 +26,7 @@
 
 #include <hip/hip_bf16.h>
 
+#include "invert_index.hpp"
 #include "knn_select.hpp"
 #include "tpg_common.hpp"
 
@@ -378,28 +379,42 @@ int knn_launch(const float *p1, const float *p2, const int64_t *len1, const int6
     return TPG_OK;
 }
 
-// grads of both Chamfer directions; all contributions land by atomics (tolerance
-// 1e-5 against the ordered CPU sum).
-__global__ __launch_bounds__(256) void chamfer_bwd_kernel(
+// Gradients of both Chamfer directions WITHOUT float atomics (round 3): every output point is written once.
+//   out[i] = the point's own term 2 g[i] (a_i - b_nn[i])  and  - sum over the entries j of the inverted
+//   index of the OTHER direction (nn2[j] == i, ascending j) of 2 g2[j] (b_j - a_i)
+// in the order the oracle's two loops produce them (oracle/tpgref.c tpgref_chamfer_bwd_f32: source points take
+// their own term first, target points take it last), so the result is bit-identical to it.
+template <bool OWN_FIRST>
+__global__ __launch_bounds__(256) void chamfer_bwd_gather_kernel(
     const float *__restrict__ a, const float *__restrict__ bcloud, int B, int N, int M,
-    const int64_t *__restrict__ nn, const float *__restrict__ g, float *__restrict__ ga,
-    float *__restrict__ gb) {
+    const int64_t *__restrict__ nn, const float *__restrict__ g, const int32_t *__restrict__ offs,
+    const int32_t *__restrict__ list, const float *__restrict__ g2, float *__restrict__ ga) {
     const long long t = (long long)blockIdx.x * blockDim.x + threadIdx.x;
     if (t >= (long long)B * N) return;
-    const int b = (int)(t / N);
+    const int b = (int)(t / N), i = (int)(t - (long long)b * N);
     long long j = nn[t];
     j = j < 0 ? 0 : (j >= M ? M - 1 : j);
     const float gg = 2.0f * g[t];
     const float *pa = a + (size_t)t * 3;
     const float *pb = bcloud + ((size_t)b * M + j) * 3;
-    float *oa = ga + (size_t)t * 3;
-    float *ob = gb + ((size_t)b * M + j) * 3;
-#pragma unroll
-    for (int c = 0; c < 3; ++c) {
-        const float v = gg * (pa[c] - pb[c]);
-        atomicAdd(oa + c, v);
-        atomicAdd(ob + c, -v);
+    const float ax = pa[0], ay = pa[1], az = pa[2];
+    float acc[3] = {0.0f, 0.0f, 0.0f};
+    const float own[3] = {gg * (ax - pb[0]), gg * (ay - pb[1]), gg * (az - pb[2])};
+    if (OWN_FIRST) { acc[0] += own[0]; acc[1] += own[1]; acc[2] += own[2]; }
+    const int32_t *of = offs + (size_t)b * (N + 1);
+    const int32_t *ls = list + (size_t)b * M;
+    const int p1 = of[i + 1];
+    for (int p = of[i]; p < p1; ++p) {
+        const int e = ls[p];                       // a point of the other cloud whose nearest neighbour is i
+        const float h = 2.0f * g2[(size_t)b * M + e];
+        const float *q = bcloud + ((size_t)b * M + e) * 3;
+        acc[0] -= h * (q[0] - ax);
+        acc[1] -= h * (q[1] - ay);
+        acc[2] -= h * (q[2] - az);
     }
+    if (!OWN_FIRST) { acc[0] += own[0]; acc[1] += own[1]; acc[2] += own[2]; }
+    float *oa = ga + (size_t)t * 3;
+    oa[0] = acc[0]; oa[1] = acc[1]; oa[2] = acc[2];
 }
 
 }  // namespace
@@ -437,20 +452,35 @@ extern "C" int tpg_chamfer_fwd_f32(const float *src, const float *tgt, int B, in
     return knn_launch<false>(tgt, src, nullptr, nullptr, B, M, N, 3, 1, -1.0f, d2, i2, tpg_stream(stream));
 }
 
+extern "C" size_t tpg_chamfer_bwd_workspace_bytes(int B, int N, int M) {
+    if (B <= 0 || N <= 0 || M <= 0) return 0;
+    // per direction: offs (B, dest + 1) + list (B, entries) + radix scratch (B, entries)
+    return sizeof(int32_t) * ((size_t)B * ((size_t)N + 1 + 2 * (size_t)M) + (size_t)B * ((size_t)M + 1 + 2 * (size_t)N)) + 64;
+}
+
 extern "C" int tpg_chamfer_bwd_f32(const float *src, const float *tgt, int B, int N, int M,
                                    const int64_t *i1, const int64_t *i2, const float *g1,
-                                   const float *g2, float *gsrc, float *gtgt, void *stream) {
+                                   const float *g2, float *gsrc, float *gtgt, void *ws, void *stream) {
     if (B < 0 || N <= 0 || M <= 0) return TPG_ERR_ARG;
     if (B == 0) return TPG_OK;
-    if (!src || !tgt || !i1 || !i2 || !g1 || !g2 || !gsrc || !gtgt) return TPG_ERR_ARG;
+    if (!src || !tgt || !i1 || !i2 || !g1 || !g2 || !gsrc || !gtgt || !ws) return TPG_ERR_ARG;
     hipStream_t st = tpg_stream(stream);
-    if (hipMemsetAsync(gsrc, 0, sizeof(float) * (size_t)B * N * 3, st) != hipSuccess) return TPG_ERR_LAUNCH;
-    if (hipMemsetAsync(gtgt, 0, sizeof(float) * (size_t)B * M * 3, st) != hipSuccess) return TPG_ERR_LAUNCH;
+    // inverted nearest-neighbour indices: source point <- the target points that chose it (i2), and vice versa
+    int32_t *offs_s = static_cast<int32_t *>(ws);
+    int32_t *list_s = offs_s + (size_t)B * (N + 1);
+    int32_t *tmp_s = list_s + (size_t)B * M;
+    int32_t *offs_t = tmp_s + (size_t)B * M;
+    int32_t *list_t = offs_t + (size_t)B * (M + 1);
+    int32_t *tmp_t = list_t + (size_t)B * N;
+    int rc = tpg_inv::launch<int64_t>(i2, B, N, M, offs_s, list_s, tmp_s, st);
+    if (rc) return rc;
+    rc = tpg_inv::launch<int64_t>(i1, B, M, N, offs_t, list_t, tmp_t, st);
+    if (rc) return rc;
     const long long t1 = (long long)B * N, t2 = (long long)B * M;
-    hipLaunchKernelGGL(chamfer_bwd_kernel, dim3((unsigned)((t1 + 255) / 256)), dim3(256), 0, st, src,
-                       tgt, B, N, M, i1, g1, gsrc, gtgt);
-    hipLaunchKernelGGL(chamfer_bwd_kernel, dim3((unsigned)((t2 + 255) / 256)), dim3(256), 0, st, tgt,
-                       src, B, M, N, i2, g2, gtgt, gsrc);
+    hipLaunchKernelGGL(chamfer_bwd_gather_kernel<true>, dim3((unsigned)((t1 + 255) / 256)), dim3(256), 0, st, src,
+                       tgt, B, N, M, i1, g1, offs_s, list_s, g2, gsrc);
+    hipLaunchKernelGGL(chamfer_bwd_gather_kernel<false>, dim3((unsigned)((t2 + 255) / 256)), dim3(256), 0, st, tgt,
+                       src, B, M, N, i2, g2, offs_t, list_t, g1, gtgt);
     TPG_RETURN_IF_LAUNCH_FAILED();
     return TPG_OK;
 }

@@ -15,7 +15,7 @@
 //                 lrelu(Wn f), E = We f; requires S == N)
 //
 // Backward is atomics-free: a per-cloud inverted index (destination row -> list of (s,k)
-// entries, built by one counting sort in LDS) turns the scatter-add into a gather-reduce
+// entries in ascending entry order, csrc/invert_index.hpp) turns the scatter-add into a gather-reduce
 // where each destination row is summed by one group of lanes and written exactly once.
 // Element types: fp32 and bf16 (bf16 halves the bytes of the largest tensors; arithmetic is
 // fp32 in registers, one rounding on store).
@@ -23,6 +23,7 @@
 
 #include <cstdlib>
 
+#include "invert_index.hpp"
 #include "tpg_common.hpp"
 
 namespace {
@@ -171,74 +172,7 @@ __global__ __launch_bounds__(256) void rowcombine_fwd_kernel(
     for (; t < total; t += stride) one(t);
 }
 
-// ------------------------------------------------------------------ inverted index
-// One workgroup per cloud: histogram of destinations in LDS, exclusive scan, fill.
-// offs (B,N+1), list (B,S*K) holds flat (s,k) entry ids grouped by destination.
-// The destination rows are taken in ranges of R rows (R = N when a cloud's counters fit the LDS
-// the launch was given: one pass, the usual case; larger clouds -- N_hi = 16384 and beyond -- walk
-// ceil(N/R) ranges, each a count / scan / fill pass over the cloud's entries, with the running
-// offset carried from range to range, so the lists come out in the same order for any R).
-__global__ __launch_bounds__(1024) void invert_index_kernel(const int32_t *__restrict__ idx, int N,
-                                                            int SK, int R, int32_t *__restrict__ offs,
-                                                            int32_t *__restrict__ list) {
-    extern __shared__ __attribute__((aligned(16))) int inv_smem[];  // [R] counters + [32] scan slots
-    int *cnt = inv_smem;
-    int *wsum = inv_smem + R;
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const int b = blockIdx.x;
-    const int32_t *id = idx + (size_t)b * SK;
-    int32_t *of = offs + (size_t)b * (N + 1);
-    int32_t *ls = list + (size_t)b * SK;
-    int base = 0;                                   // entries of the ranges already done
-    for (int r0 = 0; r0 < N; r0 += R) {
-        const int Rn = min(R, N - r0);
-        for (int n = tid; n < Rn; n += 1024) cnt[n] = 0;
-        __syncthreads();
-        for (int e = tid; e < SK; e += 1024) {
-            const int d = tpg_clamp_idx(id[e], N) - r0;
-            if ((unsigned)d < (unsigned)Rn) atomicAdd(&cnt[d], 1);
-        }
-        __syncthreads();
-        // exclusive scan of cnt[0..Rn): each thread owns a contiguous span
-        const int per = (Rn + 1023) / 1024;
-        const int lo = min(tid * per, Rn), hi = min(lo + per, Rn);
-        int local = 0;
-        for (int n = lo; n < hi; ++n) local += cnt[n];
-        int incl = local;
-#pragma unroll
-        for (int d = 1; d < 64; d <<= 1) {
-            const int o = __shfl_up(incl, d);
-            if (lane >= d) incl += o;
-        }
-        if (lane == 63) wsum[wave] = incl;
-        __syncthreads();
-        if (wave == 0) {
-            int w = lane < 16 ? wsum[lane] : 0;
-#pragma unroll
-            for (int d = 1; d < 16; d <<= 1) {
-                const int o = __shfl_up(w, d);
-                if (lane >= d) w += o;
-            }
-            if (lane < 16) wsum[16 + lane] = w;  // inclusive prefix of wave sums
-        }
-        __syncthreads();
-        int run = base + incl - local + (wave ? wsum[16 + wave - 1] : 0);  // exclusive prefix of this span
-        for (int n = lo; n < hi; ++n) {
-            const int c = cnt[n];
-            of[r0 + n] = run;
-            cnt[n] = run;  // becomes the fill cursor
-            run += c;
-        }
-        base += wsum[16 + 15];
-        __syncthreads();
-        for (int e = tid; e < SK; e += 1024) {
-            const int d = tpg_clamp_idx(id[e], N) - r0;
-            if ((unsigned)d < (unsigned)Rn) ls[atomicAdd(&cnt[d], 1)] = e;
-        }
-        __syncthreads();                            // cnt / wsum are rewritten by the next range
-    }
-    if (tid == 0) of[N] = SK;
-}
+// (the inverted index the backward walks: csrc/invert_index.hpp -- lists in ascending entry order)
 
 // ------------------------------------------------------------------ backward
 // one 16-byte chunk of one destination row per thread; gU (and gE for EDGE) written once.
@@ -564,26 +498,12 @@ extern "C" int tpg_rowcombine_fwd(const void *U, const void *QE, const int32_t *
 }
 
 extern "C" int tpg_invert_index(const int32_t *idx, int B, int N, int SK, int32_t *offs, int32_t *list,
-                                void *stream) {
+                                int32_t *tmp, void *stream) {
     if (B < 0 || N <= 0 || SK < 0) return TPG_ERR_ARG;
     if (B == 0) return TPG_OK;
     if (!idx || !offs || !list) return TPG_ERR_ARG;
-    // counters of one range of destination rows in LDS: the whole cloud while it fits the default
-    // 64 KB of dynamic LDS (N <= 16352), else ranges of up to 40 K rows in the CU's 160 KB
-    constexpr int kSmallRows = (64 * 1024) / (int)sizeof(int) - 32;
-    constexpr int kBigRows = 40 * 1024 - 32;
-    const int R = N <= kSmallRows ? N : (N < kBigRows ? N : kBigRows);
-    const size_t smem = sizeof(int) * ((size_t)R + 32);
-    if (smem > 64 * 1024) {
-        static bool raised = false;                 // (idempotent; a race would only set it twice)
-        if (!raised) {
-            if (hipFuncSetAttribute(reinterpret_cast<const void *>(invert_index_kernel),
-                                    hipFuncAttributeMaxDynamicSharedMemorySize, (int)(sizeof(int) * (kBigRows + 32))) != hipSuccess)
-                return TPG_ERR_UNSUPPORTED;
-            raised = true;
-        }
-    }
-    hipLaunchKernelGGL(invert_index_kernel, dim3(B), dim3(1024), smem, tpg_stream(stream), idx, N, SK, R, offs, list);
+    const int rc = tpg_inv::launch<int32_t>(idx, B, N, SK, offs, list, tmp, tpg_stream(stream));
+    if (rc) return rc;
     TPG_RETURN_IF_LAUNCH_FAILED();
     return TPG_OK;
 }

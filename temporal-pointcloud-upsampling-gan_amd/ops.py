@@ -240,8 +240,10 @@ class HipBackend:
         B, N, _ = src.shape
         M = tgt.shape[1]
         gs, gt = torch.empty_like(src), torch.empty_like(tgt)
+        # scratch for the two inverted nearest-neighbour indices (the gather form of the scatter: no float atomics)
+        ws = torch.empty(self.lib.tpg_chamfer_bwd_workspace_bytes(B, N, M) // 4, dtype=torch.int32, device=src.device)
         self._call("tpg_chamfer_bwd_f32", "chamfer_bwd", 40 * B * (N + M), src,
-                   _ptr(src), _ptr(tgt), B, N, M, _ptr(i1), _ptr(i2), _ptr(g1), _ptr(g2), _ptr(gs), _ptr(gt))
+                   _ptr(src), _ptr(tgt), B, N, M, _ptr(i1), _ptr(i2), _ptr(g1), _ptr(g2), _ptr(gs), _ptr(gt), _ptr(ws))
         return gs, gt
 
     def fps(self, xyz, m, start=None, skip_origin=True):
@@ -334,14 +336,15 @@ class HipBackend:
         SK = idx[0].numel()
         offs = torch.empty((B, N + 1), dtype=torch.int32, device=idx.device)
         lst = torch.empty((B, SK), dtype=torch.int32, device=idx.device)
+        tmp = torch.empty((B, SK), dtype=torch.int32, device=idx.device) if N > 256 else None   # radix scratch
         self._call("tpg_invert_index", "invert_index", 4 * B * (2 * SK + N + 1), idx,
-                   _ptr(idx), B, N, SK, _ptr(offs), _ptr(lst))
+                   _ptr(idx), B, N, SK, _ptr(offs), _ptr(lst), _ptr(tmp))
         return offs, lst
 
     def rowcombine_bwd(self, gout, idx, E, mode, N, slope, in_dtype, inverse=None):
         B, S, K, Cc = gout.shape
         if inverse is None:
-            inverse = _sorted_inverse(idx, N) if _DETERMINISTIC[0] else self.invert_index(idx, N)
+            inverse = self.invert_index(idx, N)
         offs, lst = inverse
         gU = torch.empty((B, N, Cc), dtype=in_dtype, device=gout.device)
         gQE = torch.empty((B, S, Cc), dtype=in_dtype, device=gout.device) if mode != 0 else None
@@ -1053,32 +1056,11 @@ def row_combine(U, QE, idx, mode, slope=0.2, out_dtype=None):
     return _RowCombine.apply(U, QE, idx, mode, float(slope), out_dtype, inverse)
 
 
-_DETERMINISTIC = [False]
-
-
 def set_deterministic(flag):
-    """Debugging aid: build inverted indices with every destination's list in ascending entry order
-    (a stable sort), so that the row gather's backward sums in a fixed order and a training step
-    is bitwise reproducible wherever no float atomic with >= 3 colliding addends is involved (both
-    discriminator updates).  The shipped kernel (tpg_invert_index) fills the lists through LDS
-    atomics: same lists, order inside a list not fixed, sums differ at rounding level from run to
-    run.  tests/test_graph_gpu.py uses this to compare a replayed step with its own body launched
-    kernel by kernel BIT FOR BIT -- a missing dependency edge in the captured graph cannot hide
-    behind "rounding".  Returns the previous setting."""
-    prev, _DETERMINISTIC[0] = _DETERMINISTIC[0], bool(flag)
-    return prev
-
-
-def _sorted_inverse(idx, N):
-    """(offs (B,N+1), list (B,SK)) int32 like tpg_invert_index, lists in ascending entry order."""
-    B = idx.shape[0]
-    flat = idx.reshape(B, -1).clamp(0, N - 1).long()
-    lst = torch.argsort(flat, dim=1, stable=True).to(torch.int32)
-    cnt = torch.zeros((B, N), dtype=torch.int32, device=idx.device)
-    cnt.scatter_add_(1, flat, torch.ones_like(flat, dtype=torch.int32))
-    offs = torch.zeros((B, N + 1), dtype=torch.int32, device=idx.device)
-    offs[:, 1:] = torch.cumsum(cnt, 1)
-    return offs, lst.contiguous()
+    """Kept for callers of round 2's debugging switch: the shipped path IS deterministic since round 3
+    (tpg_invert_index builds every list in ascending entry order, Chamfer's backward is a gather), so there
+    is nothing left to switch.  Returns True."""
+    return True
 
 
 def attach_inverse(idx, N):
@@ -1089,7 +1071,7 @@ def attach_inverse(idx, N):
     _need(idx.dtype == torch.int32 and idx.dim() == 3 and idx.is_contiguous(), "idx must be contiguous (B,S,K) int32")
     be = backend_for(idx)
     if hasattr(be, "invert_index"):
-        offs, lst = _sorted_inverse(idx, int(N)) if _DETERMINISTIC[0] else be.invert_index(idx, int(N))
+        offs, lst = be.invert_index(idx, int(N))
         idx._tpg_inverse = (int(N), offs, lst)
     return idx
 

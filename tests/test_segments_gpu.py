@@ -94,7 +94,7 @@ def _no_dropout(m):
     return m
 
 
-def _compare_modules(ma, mb, outs_a, outs_b, rtol_out=2e-3):
+def _compare_modules(ma, mb, outs_a, outs_b, rtol_out=2e-3, grad_rel=1e-2):
     for oa, ob in zip(outs_a, outs_b):
         oa, ob = oa.detach().float(), ob.detach().float()
         assert torch.allclose(oa, ob, rtol=rtol_out, atol=rtol_out * float(ob.abs().max() + 1e-6)), \
@@ -107,7 +107,9 @@ def _compare_modules(ma, mb, outs_a, outs_b, rtol_out=2e-3):
     gb = torch.cat([q.grad.reshape(-1) for (n, p), (_, q) in zip(ma.named_parameters(), mb.named_parameters())
                     if p.grad is not None and q.grad is not None])
     assert float(gb.norm()) > 0
-    assert float((ga - gb).norm() / gb.norm()) <= 1e-2
+    rel = float((ga - gb).norm() / gb.norm())
+    print("parameter gradients, relative L2 difference:", rel)
+    assert rel <= grad_rel, rel
     for (n, p), (_, q) in zip(ma.named_parameters(), mb.named_parameters()):
         if p.grad is None and q.grad is not None:      # conv bias ahead of a BatchNorm: folded, ~zero gradient
             assert n.endswith("bias") and float(q.grad.abs().max()) <= 1e-3 * float(gb.abs().max()), n
@@ -133,6 +135,42 @@ def test_tempo_discriminator_forward_passes_equals_two_forwards():
     _compare_modules(Da, Db, outs_a, outs_b)
     for x, y in zip(fa, fb):    # gradient reaching the generator's points (L2: a max-pool arg-max
         #                         flipping on a near-tie moves single entries by O(1))
+        assert float((x.grad - y.grad).norm() / (y.grad.norm() + 1e-12)) <= 3e-2
+
+
+@pytest.mark.parametrize("kind,T,N", [("fluid", 5, 2048), ("action", 8, 1024), ("fluid", 5, 16384)])
+def test_long_clip_tempo_discriminators_forward_passes_equal_two_forwards(kind, T, N):
+    """The same equivalence at the clip lengths of cfg5 (FluidTempoDis(5): 10 flow embeddings, the depth-d conv used
+    4 / 3 / 2 / 1 times per pass) and cfg4 (ActionTempoDis(8): 28) -- VERDICT r2 item 1(i): GPUTEST_r02's only
+    diverging term was the temporal discriminator's update at T = 5.  Batch 4 (with 2 clips the head's BatchNorm1d is a
+    sign network); outputs, BatchNorm running statistics, spectral-norm vectors, parameter and input gradients.  The
+    last case is cfg5's own cloud size (16384 points: first-level inverted index beyond 64 KB of counters)."""
+    from tpgan_amd.set_abstraction import ActionTempoDis, FluidTempoDis
+    from tpgan_amd.synthetic import action_clip, fluid_clip
+    torch.manual_seed(7)
+    dev = torch.device("cuda", 0)
+    B = 4
+    if kind == "fluid":
+        Da, R = _no_dropout(FluidTempoDis(T)).to(dev).train(), 0.10
+        hi1, hi2 = (fluid_clip(B, N, 4, T, seed=s, device=dev)[1] for s in (1, 2))
+    else:
+        Da, R = _no_dropout(ActionTempoDis(T)).to(dev).train(), 2.0
+        hi1, hi2 = (action_clip(B, N, 4, T, seed=s, device=dev)[1] for s in (1, 2))
+    Db = copy.deepcopy(Da)
+    fa = [h.clone().requires_grad_(True) for h in hi1]
+    fb = [h.clone().requires_grad_(True) for h in hi1]
+    outs_a = Da.forward_passes([fa, hi2], R)
+    outs_b = [Db(fb, R), Db(hi2, R)]
+    print(kind, T, "segments:", [o.flatten().tolist() for o in outs_a])
+    print(kind, T, "separate:", [o.flatten().tolist() for o in outs_b])
+    la = ((outs_a[0] - 0.1) ** 2).mean() + ((outs_a[1] - 1.0) ** 2).mean()
+    lb = ((outs_b[0] - 0.1) ** 2).mean() + ((outs_b[1] - 1.0) ** 2).mean()
+    la.backward(); lb.backward()
+    # 10 / 28 flow embeddings with a max over 32 neighbours each: more arg-max near-ties that the different
+    # association of the statistics' partial sums can flip than at T = 3 -- the gradient bound is the input
+    # gradients' 3e-2 here (measured 1.6e-2 at T = 8; the logits agree to 3e-4)
+    _compare_modules(Da, Db, outs_a, outs_b, grad_rel=3e-2)
+    for x, y in zip(fa, fb):
         assert float((x.grad - y.grad).norm() / (y.grad.norm() + 1e-12)) <= 3e-2
 
 
@@ -165,12 +203,8 @@ def _same_tensors(a, b):
         return all(_same_tensors(x, y) for x, y in zip(a, b))
     ta, tb = _plan_tensors(a), _plan_tensors(b)
     assert torch.equal(ta[0], tb[0])
-    if len(ta) == len(tb) == 3:         # inverted index: same buckets; the order inside a bucket is the
-        assert torch.equal(ta[1], tb[1])                                    # order the atomics landed in
-        pos = torch.arange(ta[2].shape[1], device=ta[2].device, dtype=torch.int32).expand_as(ta[2]).contiguous()
-        bucket = torch.searchsorted(ta[1].contiguous(), pos, right=True).long()
-        width = int(ta[2].max()) + 1
-        assert torch.equal(torch.sort(bucket * width + ta[2], 1).values, torch.sort(bucket * width + tb[2], 1).values)
+    if len(ta) == len(tb) == 3:         # inverted index: deterministic since round 3 (entries ascending per bucket)
+        assert torch.equal(ta[1], tb[1]) and torch.equal(ta[2], tb[2])
     return True
 
 
