@@ -12,7 +12,15 @@ CSRC = os.path.join(_HERE, "csrc")
 INCLUDE = os.path.join(os.path.dirname(_HERE), "include")
 LIB_PATH = os.path.join(CSRC, "libtpgan_hip.so")
 
-HIPCC_FLAGS = ["-O3", "--offload-arch=gfx950", "-ffp-contract=off", "-std=c++17", "-fPIC",
+# -fno-slp-vectorize (round 3): the SLP vectoriser turns pairs of scalar fp32 operations into packed
+# v_pk_{add,mul}_f32 with op_sel / neg modifiers.  In the furthest-point-sampling round (LDS read of the last pick ->
+# packed subtract / multiply / add -> integer min / max) that code produced WRONG picks on some MI355X hosts, only while
+# other streams kept the chip busy and up to once per few thousand rounds: one lane's running distance off, every wave
+# agreeing on the pick and its coordinates (tools/fps_wave_trace.py, tools/ab_fps.sh: 10 of 16 replayed cfg5 steps with a
+# wrong cloud against 0 of 8 with this flag on the same box, shipped build before and after).  The ISA is hazard-clean as
+# far as the LLVM tables go, so this is a hardware or hazard-table gap we cannot fix; no kernel here depends on SLP for its
+# speed (the matrix kernels are hand-scheduled, the streaming ones are bound by HBM), so the whole library is built without it.
+HIPCC_FLAGS = ["-O3", "--offload-arch=gfx950", "-ffp-contract=off", "-fno-slp-vectorize", "-std=c++17", "-fPIC",
                "-shared", "-Wall"]
 
 

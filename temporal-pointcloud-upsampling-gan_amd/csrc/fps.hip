@@ -27,6 +27,20 @@
 // concurrently (the reference issues one launch per frame per cloud batch).
 #include "tpg_common.hpp"
 
+#ifdef TPG_FPS_DEBUG
+// diagnostic build (tools/fps_wave_trace.py): every wave of the launch with gridDim.x == dbg_grid records, per round,
+// the pick it arrived at and the coordinates it then measures against
+__device__ int *tpg_fps_dbg_buf = nullptr;
+__device__ int tpg_fps_dbg_grid = 0;      // only the launch with this many clouds ...
+__device__ int tpg_fps_dbg_m = 0;         // ... this many picks, and the <256, 4, LDS copy> shape (buffer: grid*m*4*4 ints)
+extern "C" int tpg_fps_debug_set(int *buf, int grid, int m) {
+    if (hipMemcpyToSymbol(HIP_SYMBOL(tpg_fps_dbg_buf), &buf, sizeof(buf)) != hipSuccess) return -1;
+    if (hipMemcpyToSymbol(HIP_SYMBOL(tpg_fps_dbg_grid), &grid, sizeof(grid)) != hipSuccess) return -1;
+    if (hipMemcpyToSymbol(HIP_SYMBOL(tpg_fps_dbg_m), &m, sizeof(m)) != hipSuccess) return -1;
+    return 0;
+}
+#endif
+
 namespace {
 
 constexpr int FPS_LDS_POINTS = 12288;  // LDS copy of the cloud: 12 B/point -> 144 KiB max
@@ -88,6 +102,13 @@ __global__ __launch_bounds__(BLOCK) void fps_kernel(const float *__restrict__ xy
 
     for (int j = 1; j < m; ++j) {
         if (USE_LDS) { ox = sp[3 * old]; oy = sp[3 * old + 1]; oz = sp[3 * old + 2]; }
+#ifdef TPG_FPS_DEBUG
+        if (BLOCK == 256 && PPT == 4 && USE_LDS && tpg_fps_dbg_buf && (int)gridDim.x == tpg_fps_dbg_grid &&
+            m == tpg_fps_dbg_m && lane == 0) {
+            int *d = tpg_fps_dbg_buf + (((size_t)blockIdx.x * m + j) * NW + wave) * 4;
+            d[0] = old; d[1] = __float_as_int(ox); d[2] = __float_as_int(oy); d[3] = __float_as_int(oz);
+        }
+#endif
 
         int best = __float_as_int(-1.0f);
         int besti = 0;
@@ -222,7 +243,11 @@ __global__ __launch_bounds__(1024) void fps_big_kernel(const float *__restrict__
 template <int BLOCK, int PPT>
 void fps_go(const float *xyz, int B, int N, int m, int32_t *idx, const int32_t *start, int skip_origin,
             hipStream_t st) {
+#ifdef TPG_FPS_NO_LDS_COPY
+    int use_lds = 0;
+#else
     int use_lds = N <= FPS_LDS_POINTS;
+#endif
     size_t smem = 256 + 512 + (use_lds ? sizeof(float) * 3 * (size_t)N : 0);
     if (smem > 48 * 1024) {
         // opt in to > 48 KiB of dynamic LDS once per instantiation (not a stream operation, so

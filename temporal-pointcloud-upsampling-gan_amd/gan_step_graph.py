@@ -95,6 +95,21 @@ def _flatten_state(modules, optims):
     return flats
 
 
+@contextlib.contextmanager
+def _no_gc():
+    """No cyclic garbage collection while a graph is being captured or replayed: a collection there may
+    finalise an OLDER stepper's CUDAGraph objects (they sit in reference cycles), and destroying a graph /
+    freeing its pool while this thread captures or launches one aborts the process or corrupts the replay
+    (seen as host segfaults inside hipGraphLaunch in processes that build several steppers)."""
+    was_on = gc.isenabled()
+    gc.disable()
+    try:
+        yield
+    finally:
+        if was_on:
+            gc.enable()
+
+
 def _rotation_matrix_np():
     """gan_step.get_rotation_matrix (same three np.random draws, same Rz*Ry*Rx in fp32) without its
     five small torch ops: the host's share of a step is GPU idle time (tools/step_gap.py), and a
@@ -460,25 +475,16 @@ class GraphedFluidStep:
                 # with a process group alive, its watchdog thread polls events while we capture: only
                 # THIS thread's unsafe calls may invalidate the capture then
                 mode = {"capture_error_mode": "thread_local"} if self.sync.world_size > 1 else {}
-                # no cyclic garbage collection inside the capture: a collection there may finalise an OLDER
-                # stepper's CUDAGraph objects (they sit in reference cycles), and destroying a graph / freeing
-                # its pool while this thread captures aborts the process or corrupts later replays
-                gc_was_on = gc.isenabled()
-                gc.disable()
-                try:
-                    with torch.cuda.graph(g, pool=pool, **mode):
-                        try:
-                            fn()
-                        except BaseException:
-                            # leave the capture joinable: an unjoined side stream turns the original
-                            # error into "capturing stream has unjoined work" and poisons the stream
-                            self._join_sides()
-                            torch.cuda.current_stream(self.dev).wait_stream(self.branch)
-                            torch.cuda.current_stream(self.dev).wait_stream(self.branch2)
-                            raise
-                finally:
-                    if gc_was_on:
-                        gc.enable()
+                with _no_gc(), torch.cuda.graph(g, pool=pool, **mode):
+                    try:
+                        fn()
+                    except BaseException:
+                        # leave the capture joinable: an unjoined side stream turns the original
+                        # error into "capturing stream has unjoined work" and poisons the stream
+                        self._join_sides()
+                        torch.cuda.current_stream(self.dev).wait_stream(self.branch)
+                        torch.cuda.current_stream(self.dev).wait_stream(self.branch2)
+                        raise
                 pool = g.pool()
                 graphs.append((g, None if reduce_module is None else reduce_module["flat"]))
             self._graphs[update_D] = graphs
@@ -539,16 +545,17 @@ class GraphedFluidStep:
                 st = torch.cuda.current_stream(self.dev)
                 marks = [torch.cuda.Event(enable_timing=True)]
                 marks[0].record(st)
-            for g, flat in self._graphs[update_D]:
-                g.replay()
-                if marks is not None:
-                    marks.append(torch.cuda.Event(enable_timing=True))
-                    marks[-1].record(st)
-                if flat is not None:
-                    self.sync.sum_flat(flat)            # the ONE collective of the step's gradients
+            with _no_gc():
+                for g, flat in self._graphs[update_D]:
+                    g.replay()
                     if marks is not None:
                         marks.append(torch.cuda.Event(enable_timing=True))
                         marks[-1].record(st)
+                    if flat is not None:
+                        self.sync.sum_flat(flat)            # the ONE collective of the step's gradients
+                        if marks is not None:
+                            marks.append(torch.cuda.Event(enable_timing=True))
+                            marks[-1].record(st)
         # multi-GPU: the decision to leave the graph path must be COLLECTIVE -- the eager step issues
         # other all-reduces than the replay -- and it is: the two-graph form has summed the flag over
         # the ranks inside its one all-reduce

@@ -1056,13 +1056,6 @@ def row_combine(U, QE, idx, mode, slope=0.2, out_dtype=None):
     return _RowCombine.apply(U, QE, idx, mode, float(slope), out_dtype, inverse)
 
 
-def set_deterministic(flag):
-    """Kept for callers of round 2's debugging switch: the shipped path IS deterministic since round 3
-    (tpg_invert_index builds every list in ascending entry order, Chamfer's backward is a gather), so there
-    is nothing left to switch.  Returns True."""
-    return True
-
-
 def attach_inverse(idx, N):
     """Prepare the inverted index of a neighbour list idx (B,S,K) int32 into N source rows NOW
     (on the current stream) and hang it on the tensor: `row_combine` hands it to its backward,

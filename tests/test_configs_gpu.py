@@ -17,41 +17,89 @@ def _finite(d):
     return all(np.isfinite(v) for v in d.values())
 
 
-@pytest.mark.parametrize("name,batch", [("cfg5shard", 2), ("cfg4", 4)])
-def test_config_steps_eager_and_replayed(name, batch):
+def _stepper_pair(configs, name, A, clip, amp):
+    """Two steppers on deep copies of the same networks (state, optimizers) for the same clip shapes."""
+    out = []
+    for _ in range(2):
+        M = copy.deepcopy(A[:3])
+        M = (*M, tuple(torch.optim.Adam(m.parameters(), lr=g.param_groups[0]["lr"], capturable=True)
+                       for m, g in zip((M[0], M[2], M[1]), A[3])))
+        out.append((M, configs.graphed_step(name, M, clip, amp_dtype=amp)))
+    return out
+
+
+def _state(M):
+    return {f"{n}.{k}": v for n, m in zip(("G", "Ds", "Dt"), M[:3]) for k, v in m.state_dict().items()}
+
+
+@pytest.mark.parametrize("name", ["cfg5shard", "cfg4"])
+def test_config_replay_is_bitwise_its_body_and_equals_the_eager_step(name):
+    """BASELINE's cfg5 (one rank's shard: N_hi = 16384, T = 5) and cfg4 (N_hi = 2048, T = 8) at batch 4 (with two
+    clips the heads' BatchNorm1d is a sign network -- the goldens' own rule).  What is asserted is what is principled
+    (ADVICE r2):
+
+      * a replay and the SAME body launched kernel by kernel agree BIT FOR BIT -- six losses and every parameter,
+        BatchNorm statistic and spectral-norm vector of both discriminators (the generator's Adam update to 1e-5
+        relative: a few of its weight gradients are library GEMMs split along K) -- in fp32 and in bf16: the shipped path
+        is deterministic since round 3 (inverted indices in entry order, Chamfer backward as a gather, FPS exchange
+        that cannot take a stale entry), so a missing dependency edge of the captured graph cannot hide behind
+        "rounding";
+      * fp32: the replayed body (stacked generator call, fake / real batch and frames as segments) equals the eager
+        step (`gan_step`, the reference's call pattern) in all six losses to 5e-3 relative (measured 4e-4 at worst);
+      * bf16: Chamfer and mask loss of eager and replay agree to 2e-3; the four GAN terms are PRINTED, not asserted
+        -- GPUTEST_r02 (tempo_D 0.50 against 1.37) was that comparison at batch 2 with the round-2 FPS exchange
+        occasionally handing the temporal discriminator wrong centres (tools/race_trace.py), i.e. a lottery on a
+        chaotic quantity."""
     from tpgan_amd import configs
     dev = torch.device("cuda", 0)
+    batch = 4
     A = configs.build_models(name, dev, seed=5, capturable=True)
     for m in list(A[1].modules()) + list(A[2].modules()):
         if isinstance(m, torch.nn.Dropout):
-            m.p = 0.0           # (mask parity of replay and eager is test_graph_gpu's subject; here: shapes)
-    Bm = copy.deepcopy(A[:3])
-    Bm = (*Bm, tuple(torch.optim.Adam(m.parameters(), lr=g.param_groups[0]["lr"], capturable=True)
-                     for m, g in zip((Bm[0], Bm[2], Bm[1]), A[3])))
+            m.p = 0.0           # (mask parity of replay and eager is test_graph_gpu's subject)
     clips = [configs.make_clip(name, batch=batch, seed=s, device=dev) for s in (1, 2)]
     spec = configs.SPECS[name]
     assert clips[0][1][0].shape == (batch, spec["points"], 3) and len(clips[0][1]) == spec["frames"]
     assert clips[0][0][0].shape == (batch, spec["points"] // spec["ratio"], 3)
-    stepper = configs.graphed_step(name, Bm, clips[0], amp_dtype=torch.bfloat16)
-    configs.seed_host_rng(3)
-    le = configs.eager_step(name, A, clips[0], 12, amp_dtype=torch.bfloat16)
-    configs.seed_host_rng(3)
-    lg = stepper(clips[0][0], clips[0][1], 12)
-    print(name, "eager :", le)
-    print(name, "replay:", lg)
-    assert _finite(le) and _finite(lg) and le["tempo_D_loss"] > 0 and lg["tempo_D_loss"] > 0
-    assert set(le) == set(lg)
-    # same state, same host draws, bf16 in both: the RNG-free Chamfer term agrees tightly
-    k = "Chamfer_distance_no_norm"
-    assert abs(le[k] - lg[k]) <= 2e-3 * max(1.0, abs(le[k])), (le[k], lg[k])
-    # the GAN terms of an untrained step sit on discrete decisions that a 1e-7 change of the inputs flips
-    # (tests/test_graph_gpu.py::test_step_sensitivity...): the eager step and the re-organised replayed body
-    # agree on them only loosely
-    for k in ("tempo_G_loss", "tempo_D_loss", "spatial_G_loss", "spatial_D_loss"):
-        assert abs(le[k] - lg[k]) <= 0.5, (k, le[k], lg[k])
-    for it, c in ((13, clips[1]), (14, clips[0])):
-        lg = stepper(c[0], c[1], it)
-        assert _finite(lg) and (lg["tempo_D_loss"] > 0) == (it % 2 == 0)
+    for amp in (None, torch.bfloat16):
+        tag = f"{name} {'fp32' if amp is None else 'bf16'}"
+        (Ma, sa), (Mb, sb) = _stepper_pair(configs, name, A, clips[0], amp)
+        E = copy.deepcopy(A[:3])
+        E = (*E, tuple(torch.optim.Adam(m.parameters(), lr=g.param_groups[0]["lr"], capturable=True)
+                       for m, g in zip((E[0], E[2], E[1]), A[3])))
+        configs.seed_host_rng(3)
+        le = configs.eager_step(name, E, clips[0], 12, amp_dtype=amp)
+        configs.seed_host_rng(3)
+        lr_ = sa(clips[0][0], clips[0][1], 12)
+        configs.seed_host_rng(3)
+        lb = sb(clips[0][0], clips[0][1], 12, launch_eagerly=True)
+        print(tag, "eager :", le)
+        print(tag, "replay:", lr_)
+        print(tag, "body  :", lb)
+        assert _finite(le) and _finite(lr_) and set(le) == set(lr_) and le["tempo_D_loss"] > 0 and lr_["tempo_D_loss"] > 0
+        assert lr_ == lb, (tag, "replay and body losses differ", lr_, lb)
+        sa_, sb_ = _state(Ma), _state(Mb)
+        diff = [(k, float((sa_[k].float() - sb_[k].float()).abs().max())) for k in sa_
+                if not k.startswith("G.") and not torch.equal(sa_[k], sb_[k])]
+        assert not diff, (tag, f"{len(diff)} discriminator state tensors differ between replay and body", diff[:5])
+        g0 = torch.cat([p.detach().reshape(-1) for p in A[0].parameters()])
+        ga = torch.cat([p.detach().reshape(-1) for p in Ma[0].parameters()]) - g0
+        gb = torch.cat([p.detach().reshape(-1) for p in Mb[0].parameters()]) - g0
+        rel = float((ga - gb).norm() / ga.norm())
+        print(tag, f"generator update, replay vs body: relative L2 difference {rel:.2e}")
+        assert rel <= 1e-5, (tag, rel)
+        if amp is None:
+            for k in le:
+                assert abs(le[k] - lr_[k]) <= 5e-3 * max(1.0, abs(le[k])), (tag, k, le[k], lr_[k])
+        else:
+            for k in ("Chamfer_distance_no_norm", "masking_loss"):
+                if k in le:
+                    assert abs(le[k] - lr_[k]) <= 2e-3 * max(1.0, abs(le[k])), (tag, k, le[k], lr_[k])
+        # keeps replaying: a G-only iteration on another clip, then G+D again
+        for it, c in ((13, clips[1]), (14, clips[0])):
+            lg = sa(c[0], c[1], it)
+            assert _finite(lg) and (lg["tempo_D_loss"] > 0) == (it % 2 == 0)
+        del sa, sb
 
 
 def test_cfg5_discriminators_forward_backward_at_16384_points():

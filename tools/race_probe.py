@@ -51,6 +51,7 @@ def main():
         if variant in ("rocblas", "hipblaslt"):
             torch.backends.cuda.preferred_blas_library(variant)
         seen = {}
+        plans = []
         for r in range(reps):
             M = copy.deepcopy(A[:3])
             M = (*M, tuple(torch.optim.Adam(m.parameters(), lr=g.param_groups[0]["lr"], capturable=True)
@@ -75,6 +76,8 @@ def main():
                     tot += int(v.sum(dtype=torch.int64))
                 keep[kname] = tot & 0xffffffffff
             key = (tuple(sorted(losses.items())), tuple(checksum(m) for m in M[:3]), tuple(sorted(keep.items())))
+            plans.append({kname: [t.detach().cpu() for t in _plan_tensors(st._keep.get(kname))]
+                          for kname in ("plan_true_s", "plan_true_t", "trues", "true_s")})
             seen[key] = seen.get(key, 0) + 1
             del st
         print(f"{name} batch {batch} {amp_s} {mode} variant {variant}: {len(seen)} distinct outcomes in {reps} runs")
@@ -83,6 +86,19 @@ def main():
             print(f"   x{n}: tempo_D {d['tempo_D_loss']:.7f} spatial_D {d['spatial_D_loss']:.7f} tempo_G {d['tempo_G_loss']:.7f} "
                   f"spatial_G {d['spatial_G_loss']:.7f} CD {d['Chamfer_distance_no_norm']:.5f}  state sums G/Ds/Dt {sums}")
             print("        kept:", dict(keep))
+        # which plan tensor differs, and where (reference = the first run whose outcome is the most frequent one)
+        import collections
+        sig = [tuple(tuple(int(t.long().sum()) for t in p[k]) for k in sorted(p)) for p in plans]
+        ref = sig.index(collections.Counter(sig).most_common(1)[0][0])
+        for r, p in enumerate(plans):
+            for kname in p:
+                for ti, (a, b) in enumerate(zip(plans[ref][kname], p[kname])):
+                    if not torch.equal(a, b):
+                        ne = (a != b)
+                        first = torch.nonzero(ne.reshape(-1))[0].item()
+                        idx = list(torch.unravel_index(torch.tensor(first), a.shape))
+                        print(f"   run {r}: {kname}[{ti}] shape {tuple(a.shape)} {a.dtype}: {int(ne.sum())} elements differ, first at "
+                              f"{[int(i) for i in idx]}: ref {a.reshape(-1)[first:first + 6].tolist()} got {b.reshape(-1)[first:first + 6].tolist()}")
 
 
 if __name__ == "__main__":
