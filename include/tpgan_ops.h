@@ -367,6 +367,32 @@ int tpg_small_tail_bwd(const void *h, const void *out, const void *gout, const u
                        const float *W1, const float *W2, float slope1, float slope2, long long P, int K, int H,
                        int C1, int C2, void *gh, float *dW1, float *dW2, void *ws, void *stream);
 
+/* ---- row-wise linear layers of any small channel count (csrc/rowlinear.hip, round 3) -------------------------
+ * The 1x1 convolutions that are NOT inside a fused tail: the generator's node / edge affines, bottlenecks,
+ * decoders and skip layers (gcn_lib/pointnet/gcn.py:176-180,207-211,253-277; upsampling_network.py:44-104), the
+ * first layer of every shared MLP of the discriminators applied to the un-grouped points
+ * (discriminator.py:63-78,140-148,276-282: Cin = 3, 6, 131, 259, 515) and the heads' linears
+ * (discriminator.py:503-516,598-612) -- in the reference: cuDNN / cuBLAS calls plus separate bias / activation kernels.
+ *     y[p, o] = lrelu_slope( sum_c x[p, c] * W[seg(p)][o, c] + bias[o] )
+ * x (P, Cin) and y (P, Cout) channels-last rows, f32 or bf16 (tpg_dtype); W (nseg, Cout, Cin) f32: nseg equal
+ * consecutive row blocks with their own weights (P % nseg == 0, and (P / nseg) % 64 == 0 when nseg > 1;
+ * Cin, Cout <= 1000: tpg_rowlinear_supported);
+ * bias (Cout) f32 or NULL; slope in [0, 1], 1 = no activation.  fp32 products and accumulation on
+ * v_mfma_f32_16x16x4_f32.  x, y, W 16-byte aligned.
+ * Backward (y = the forward's output, needed when slope != 1: the activation's derivative is taken from its sign):
+ *   tpg_rowlinear_dgrad: dx (P, Cin) = (gy * lrelu'(y)) . W
+ *   tpg_rowlinear_wgrad: dW (nseg, Cout, Cin) f32 = (gy * lrelu'(y))^T . x per segment; db (Cout) f32 or NULL = its
+ *                        column sums over all segments; row slabs summed in slab order (bitwise reproducible);
+ *                        ws: tpg_rowlinear_wgrad_workspace_bytes(P, nseg, Cin, Cout, db != NULL) bytes. */
+int tpg_rowlinear_supported(int Cin, int Cout, int has_bias);
+size_t tpg_rowlinear_wgrad_workspace_bytes(long long P, int nseg, int Cin, int Cout, int has_bias);
+int tpg_rowlinear_fwd(const void *x, int dtype_in, const float *W, const float *bias, long long P, int nseg, int Cin,
+                      int Cout, float slope, void *y, int dtype_out, void *stream);
+int tpg_rowlinear_dgrad(const void *gy, const void *y, int dtype_g, const float *W, long long P, int nseg, int Cin,
+                        int Cout, float slope, void *dx, int dtype_x, void *stream);
+int tpg_rowlinear_wgrad(const void *x, int dtype_x, const void *gy, const void *y, int dtype_g, long long P, int nseg,
+                        int Cin, int Cout, float slope, float *dW, float *db, void *ws, void *stream);
+
 #ifdef __cplusplus
 }
 #endif

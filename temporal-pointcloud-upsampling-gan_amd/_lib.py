@@ -56,12 +56,15 @@ SIGNATURES = {
     "tpg_mlp_bn_bwd_apply_rowsum": [_P, _P, _P, _P, _L, _I, _I, _I, _P, _P, _P],
     "tpg_small_tail_fwd": [_P, _I, _P, _P, _F, _F, _L, _I, _I, _I, _I, _P, _P, _P],
     "tpg_small_tail_bwd": [_P, _P, _P, _P, _I, _P, _P, _F, _F, _L, _I, _I, _I, _I, _P, _P, _P, _P, _P],
+    "tpg_rowlinear_fwd": [_P, _I, _P, _P, _L, _I, _I, _I, _F, _P, _I, _P],
+    "tpg_rowlinear_dgrad": [_P, _P, _I, _P, _L, _I, _I, _I, _F, _P, _I, _P],
+    "tpg_rowlinear_wgrad": [_P, _I, _P, _P, _I, _L, _I, _I, _I, _F, _P, _P, _P, _P],
     "tpg_mlp_fwd": [_P, _L, _I, _I, _I, _P, _I, _F, _P, _I, _P, _F, _F, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P],
 }
 SIZE_GETTERS = ("tpg_rowbn_workspace_bytes", "tpg_mlp_workspace_bytes")
 OTHER_GETTERS = ("tpg_spectral_norm_multi_stride", "tpg_spectral_norm_multi_bwd_scratch",
                  "tpg_mlp_wgrad_workspace_bytes", "tpg_frnn_grid_workspace_bytes", "tpg_small_tail_workspace_bytes",
-                 "tpg_chamfer_bwd_workspace_bytes")
+                 "tpg_chamfer_bwd_workspace_bytes", "tpg_rowlinear_wgrad_workspace_bytes", "tpg_rowlinear_supported")
 STRING_GETTERS = ("tpg_version", "tpg_target_arch")
 
 STATUS = {0: "TPG_OK", -1: "TPG_ERR_ARG", -2: "TPG_ERR_LAUNCH", -3: "TPG_ERR_UNSUPPORTED"}
@@ -104,6 +107,10 @@ def load():
     lib.tpg_frnn_grid_workspace_bytes.restype = C.c_size_t
     lib.tpg_chamfer_bwd_workspace_bytes.argtypes = [C.c_int, C.c_int, C.c_int]
     lib.tpg_chamfer_bwd_workspace_bytes.restype = C.c_size_t
+    lib.tpg_rowlinear_wgrad_workspace_bytes.argtypes = [C.c_longlong, C.c_int, C.c_int, C.c_int, C.c_int]
+    lib.tpg_rowlinear_wgrad_workspace_bytes.restype = C.c_size_t
+    lib.tpg_rowlinear_supported.argtypes = [C.c_int, C.c_int, C.c_int]
+    lib.tpg_rowlinear_supported.restype = C.c_int
     _lib = lib
     return lib
 

@@ -15,13 +15,13 @@
 //     inside a wave the lowest lane and among the waves the lowest wave hold
 //     the smallest index.  One 32-bit DPP max reduction of the value, then
 //     ballot(value == max) -> first set lane -> v_readlane of its index: the
-//     index never goes through a reduction of its own.  NO barrier in the
-//     round (round 3): each wave drops its (value, index | round number)
-//     into a double-buffered LDS slot, every wave polls the <=16 slots until
-//     all carry this round's number and re-reduces them redundantly, so no
-//     broadcast step is needed and a stale entry can never pass for a fresh
-//     one (see the comment at the exchange).  (A round is VALU-issue bound
+//     index never goes through a reduction of its own.  ONE barrier per
+//     round: each wave drops its (value, index) into a double-buffered LDS
+//     slot and every wave re-reduces the <=16 slots redundantly, so no second
+//     barrier and no broadcast step are needed.  (A round is VALU-issue bound
 //     on its one CU: ~80 wave instructions x 16 waves.)
+//   * built WITHOUT the SLP vectoriser (build.py): the packed fp32 math it makes of this round
+//     gave wrong picks on some hosts under multi-stream load (round 3).
 //   * clouds of <=256 points run in a single wave with no barrier at all.
 // Callers batch frames x {fake,true} x batch into B so that B workgroups run
 // concurrently (the reference issues one launch per frame per cloud batch).
@@ -139,7 +139,7 @@ __global__ __launch_bounds__(BLOCK) void fps_kernel(const float *__restrict__ xy
             }
         }
         int win = wave;
-#ifdef TPG_FPS_BARRIER_EXCHANGE          // the round-2 exchange, kept for A/B runs of tools/race_trace.py
+#ifndef TPG_FPS_POLL_EXCHANGE            // default: one barrier per round, double-buffered slots
         if constexpr (NW > 1) {
             int2 *slot = slots + (j & 1) * 16;
             if (lane == 0) slot[wave] = make_int2(mx, bi);
@@ -151,13 +151,12 @@ __global__ __launch_bounds__(BLOCK) void fps_kernel(const float *__restrict__ xy
         }
 #else
         if constexpr (NW > 1) {
-            // Exchange WITHOUT a barrier (round 3): every entry carries its round number, and a wave polls the NW
-            // entries until all of them carry THIS round's.  The round-2 form (s_barrier + double-buffered slots)
-            // was observed, on some MI355X hosts and only with several streams busy, to hand a wave another wave's
-            // entry from two rounds earlier (tools/race_trace.py: picks replaced by an index out of the stale wave's
-            // range, distances consistent with round j-2) -- with the tag a reader can never take a stale entry
-            // for a fresh one.  Double buffering stays: a wave writes its round-(j+2) entry only after it has seen
-            // every wave's round-(j+1) entry, i.e. after every wave has finished reading round j.
+            // Alternative exchange WITHOUT a barrier (-DTPG_FPS_POLL_EXCHANGE; tools/tune_fps.py "default" vs "barrier":
+            // 0.1 us per round slower, kept because it needs nothing but LDS ordering): every entry carries its
+            // round number, and a wave polls the NW entries until all of them carry THIS round's.  Double buffering
+            // stays: a wave writes its round-(j+2) entry only after it has seen every wave's round-(j+1) entry, i.e.
+            // after every wave has finished reading round j.  (Written while hunting the wrong picks that turned out
+            // to come from SLP-vectorised packed math -- see build.py; both exchanges are correct without it.)
             const unsigned tag = (unsigned)j << 16;                        // j <= 16383 (N <= 16384 here)
             volatile int2 *slot = slots + (j & 1) * 16;
             if (lane == 0) {
@@ -191,9 +190,7 @@ __global__ __launch_bounds__(1024) void fps_big_kernel(const float *__restrict__
                                                        int32_t *__restrict__ idx,
                                                        const int32_t *__restrict__ start, int skip_origin) {
     __shared__ tpg_u64 slots[2][16];
-    __shared__ int tags[2][16];            // round number of each entry (see fps_kernel: exchange without a barrier)
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    if (tid < 32) tags[tid >> 4][tid & 15] = -1;
     const float *x = xyz + (size_t)blockIdx.x * N * 3;
     float *tp = temp + (size_t)blockIdx.x * N;
     int32_t *out = idx + (size_t)blockIdx.x * m;
@@ -219,16 +216,9 @@ __global__ __launch_bounds__(1024) void fps_big_kernel(const float *__restrict__
         }
         tpg_u64 key = best >= 0.0f ? fps_key(best, besti) : 0ull;
         key = tpg_wave_max_u64(key);
-        volatile tpg_u64 *sl = slots[j & 1];
-        volatile int *tg = tags[j & 1];
-        if (lane == 0) { sl[wave] = key; tg[wave] = j; }       // (a wave's LDS writes land in program order)
-        // the running distances of round j+1 are read by the threads that wrote them: no barrier needed for tp[]
-        int seen;
-        tpg_u64 v;
-        do {
-            seen = lane < 16 ? tg[lane] : j;
-            v = lane < 16 ? sl[lane] : 0ull;
-        } while (__ballot(seen != j) != 0ull);
+        if (lane == 0) slots[j & 1][wave] = key;
+        __syncthreads();
+        tpg_u64 v = lane < 16 ? slots[j & 1][lane] : 0ull;
         tpg_u64 o;
         o = tpg_dpp_u64<0xB1>(v); v = o > v ? o : v;
         o = tpg_dpp_u64<0x4E>(v); v = o > v ? o : v;

@@ -265,13 +265,32 @@ class _TallLinearSeg(torch.autograd.Function):
         return dx, dw, None
 
 
-def rows_matmul_seg(x, w):
-    """x (nseg*P, Cin) rows in nseg equal blocks, w (nseg, Cout, Cin): block s times w[s]^T."""
+def _act(y, slope):
+    if slope == 1.0:
+        return y
+    return torch.relu(y) if slope == 0.0 else F.leaky_relu(y, slope)
+
+
+def _hand_dtype(x):
+    """Output dtype of a hand-written row-linear launch on x: the autocast dtype when autocast is on (what the
+    library GEMM under autocast would return), else x's own."""
+    if x.is_cuda and torch.is_autocast_enabled():
+        dt = torch.get_autocast_dtype('cuda')
+        return dt if dt in (torch.float32, torch.bfloat16) else None
+    return x.dtype if x.dtype in (torch.float32, torch.bfloat16) else None
+
+
+def rows_matmul_seg(x, w, slope=1.0):
+    """x (nseg*P, Cin) rows in nseg equal blocks, w (nseg, Cout, Cin): lrelu_slope(block s times w[s]^T)."""
+    hd = _hand_dtype(x)
+    if hd is not None and x.dtype in (torch.float32, torch.bfloat16) and ops.row_linear_supported(x, w, w.shape[0]):
+        with torch.autocast(device_type=x.device.type, enabled=False):       # csrc/rowlinear.hip: one launch, fp32 products
+            return ops.row_linear(x, w, None, slope, w.shape[0], hd)
     dtype = torch.get_autocast_dtype('cuda') if (x.is_cuda and torch.is_autocast_enabled()) else x.dtype
     if dtype not in (torch.float32, torch.bfloat16, torch.float16):
         dtype = torch.float32
     with torch.autocast(device_type=x.device.type, enabled=False):
-        return _TallLinearSeg.apply(x, w, dtype)
+        return _act(_TallLinearSeg.apply(x, w, dtype), slope)
 
 
 def _split_k(P, cout, cin):
@@ -285,8 +304,19 @@ def _split_k(P, cout, cin):
 TALL_ROWS = 8192   # row counts from which the split-K weight gradient pays
 
 
-def rows_matmul(x, w, bias=None):
-    """x (...,Cin) @ w (Cout,Cin)^T [+ bias] on rows; tall inputs use the split-K backward."""
+def rows_matmul(x, w, bias=None, slope=1.0):
+    """lrelu_slope(x (...,Cin) @ w (Cout,Cin)^T [+ bias]) on rows (slope 1 = no activation, 0 = ReLU): the library GEMM
+    (tall inputs with the split-K backward) + the activation; with ops.ROW_LINEAR on, ONE hand-written launch
+    (ops.row_linear, csrc/rowlinear.hip: bias, activation and the output's rounding in the epilogue) -- correct, but
+    measured slower than the library at every shape of the step, hence off by default (see ops.ROW_LINEAR)."""
+    hd = _hand_dtype(x)
+    if hd is not None and x.dtype in (torch.float32, torch.bfloat16) and ops.row_linear_supported(x, w):
+        with torch.autocast(device_type=x.device.type, enabled=False):
+            return ops.row_linear(x, w, bias, slope, 1, hd)
+    return _act(_rows_matmul_lib(x, w, bias), slope)
+
+
+def _rows_matmul_lib(x, w, bias=None):
     lead = x.shape[:-1]
     P = x.numel() // x.shape[-1] if x.numel() else 0
     if P >= TALL_ROWS and x.is_cuda and torch.is_grad_enabled() and w.requires_grad:
@@ -298,15 +328,28 @@ def rows_matmul(x, w, bias=None):
     return F.linear(x, w, bias)
 
 
-def rows_linear(conv, x):
-    """Apply a bare 1x1 Conv2d (weight (Cout,Cin,1,1), optional bias) to rows (...,Cin)."""
-    return rows_matmul(x, conv.weight.view(conv.out_channels, -1), conv.bias)
+def rows_linear(conv, x, slope=1.0):
+    """Apply a bare 1x1 Conv2d (weight (Cout,Cin,1,1), optional bias) [+ LeakyReLU(slope)] to rows (...,Cin)."""
+    return rows_matmul(x, conv.weight.view(conv.out_channels, -1), conv.bias, slope)
 
 
 def rows_seq(seq, x):
-    """Run a Sequential of bare 1x1 convs and LeakyReLUs on rows (norm == 'none' only)."""
-    for m in seq:
-        x = rows_linear(m, x) if isinstance(m, nn.Conv2d) else m(x)
+    """Run a Sequential of bare 1x1 convs and LeakyReLUs on rows (norm == 'none' only); a conv and the LeakyReLU
+    after it are one launch."""
+    mods = list(seq)
+    i = 0
+    while i < len(mods):
+        m = mods[i]
+        if isinstance(m, nn.Conv2d):
+            nxt = mods[i + 1] if i + 1 < len(mods) else None
+            if isinstance(nxt, nn.LeakyReLU) and 0.0 <= nxt.negative_slope <= 1.0:
+                x = rows_linear(m, x, float(nxt.negative_slope))
+                i += 1
+            else:
+                x = rows_linear(m, x)
+        else:
+            x = m(x)
+        i += 1
     return x
 
 
@@ -400,7 +443,7 @@ class EdgeConv(nn.Module):
             idx = self.dilated_knn_graph(pos if pos is not None else x).to(torch.int32).contiguous()
         with no_autocast(x):
             xf = x.float()
-            A = F.leaky_relu(rows_linear(self.node_affine[0], xf), 0.2)  # (B,N,H)
+            A = rows_linear(self.node_affine[0], xf, 0.2)                # (B,N,H), LeakyReLU in the epilogue
             E = rows_linear(self.edge_affine[0], xf)
         h = ops.row_combine(A, E, idx, ops.ROW_EDGE, slope=0.2, out_dtype=amp_dtype(x))   # (B,N,k,H)
         if self.mlp_layer:

@@ -657,6 +657,44 @@ class HipBackend:
             self._sn_plans[key] = plan
         return plan
 
+    # ---- row-wise linear layers of any small channel count (csrc/rowlinear.hip) -------------
+    def rowlinear_fwd(self, x, W, bias, nseg, slope, out_dtype):
+        P, Cin = x.shape
+        Cout = W.shape[-2]
+        y = torch.empty((P, Cout), dtype=out_dtype, device=x.device)
+        self._call("tpg_rowlinear_fwd", "rowlinear_fwd", x.element_size() * P * Cin + y.element_size() * P * Cout + 4 * W.numel(), x,
+                   _ptr(x), _DTYPE_CODE[x.dtype], _ptr(W), _ptr(bias), P, int(nseg), Cin, Cout, float(slope), _ptr(y),
+                   _DTYPE_CODE[out_dtype], flops=2 * P * Cin * Cout)
+        return y
+
+    def rowlinear_dgrad(self, gy, y, W, nseg, slope, x_dtype):
+        P, Cout = gy.shape
+        Cin = W.shape[-1]
+        dx = torch.empty((P, Cin), dtype=x_dtype, device=gy.device)
+        self._call("tpg_rowlinear_dgrad", "rowlinear_dgrad", gy.element_size() * P * Cout * (2 if y is not None else 1)
+                   + dx.element_size() * P * Cin + 4 * W.numel(), gy,
+                   _ptr(gy), _ptr(y), _DTYPE_CODE[gy.dtype], _ptr(W), P, int(nseg), Cin, Cout, float(slope), _ptr(dx),
+                   _DTYPE_CODE[x_dtype], flops=2 * P * Cin * Cout)
+        return dx
+
+    def rowlinear_wgrad(self, x, gy, y, nseg, slope, need_bias):
+        P, Cin = x.shape
+        Cout = gy.shape[1]
+        dW = torch.empty((nseg, Cout, Cin), dtype=torch.float32, device=x.device)
+        db = torch.empty(Cout, dtype=torch.float32, device=x.device) if need_bias else None
+        need = self.lib.tpg_rowlinear_wgrad_workspace_bytes(P, int(nseg), Cin, Cout, int(bool(need_bias))) // 4 + 4
+        key = ("rowlinear", x.device, torch.cuda.current_stream(x.device).cuda_stream)
+        ws = self._ws.get(key)
+        if ws is None or ws.numel() < need:
+            self._retire(ws)
+            ws = torch.empty(need, dtype=torch.float32, device=x.device)
+            self._ws[key] = ws
+        self._call("tpg_rowlinear_wgrad", "rowlinear_wgrad", x.element_size() * P * Cin + gy.element_size() * P * Cout
+                   * (2 if y is not None else 1), x,
+                   _ptr(x), _DTYPE_CODE[x.dtype], _ptr(gy), _ptr(y), _DTYPE_CODE[gy.dtype], P, int(nseg), Cin, Cout,
+                   float(slope), _ptr(dW), _ptr(db), _ptr(ws), flops=2 * P * Cin * Cout)
+        return dW, db
+
     def spectral_norm_multi_fwd(self, Ws, us, vs, uses, iterate, eps):
         """-> (flat output buffer, plan); output layout in include/tpgan_ops.h."""
         plan = self._sn_plan(Ws, us, vs, uses)
@@ -1382,6 +1420,80 @@ def mlp_tail(x0, bns, weights, slopes, K, nseg=1, shifts=None):
     cfg = (int(nseg), int(K), tuple(float(s) for s in slopes), tuple(eps), tuple(moms), tuple(states),
            tuple(None if s is None else s.detach().float().contiguous() for s in shifts))
     return _MlpTail.apply(x0.contiguous(), cfg, *tensors)
+
+
+# ---------------------------------------------------------------------- row-wise linear layers
+class _RowLinear(torch.autograd.Function):
+    """y = lrelu_slope(x @ W[seg]^T + bias) on rows (csrc/rowlinear.hip); backward from the saved OUTPUT (the sign
+    of y is the sign of the pre-activation), one launch for dx, two (slabs + ordered reduce) for dW / db."""
+
+    @staticmethod
+    def forward(ctx, x, W, bias, nseg, slope, out_dtype):
+        be = backend_for(x)
+        Wf = W if W.dtype == torch.float32 else W.float()
+        Wf = Wf.contiguous()
+        bf = None if bias is None else bias.float().contiguous()
+        y = be.rowlinear_fwd(x, Wf, bf, nseg, slope, out_dtype)
+        ctx.save_for_backward(x, Wf, y if slope != 1.0 else None)
+        ctx.cfg = (int(nseg), float(slope), W.dtype, W.shape, None if bias is None else bias.dtype)
+        return y
+
+    @staticmethod
+    def backward(ctx, gy):
+        x, Wf, y = ctx.saved_tensors
+        nseg, slope, w_dtype, w_shape, b_dtype = ctx.cfg
+        be = backend_for(x)
+        gy = gy.contiguous()
+        if gy.dtype not in _DTYPE_CODE:
+            gy = gy.float()
+        if y is not None and y.dtype != gy.dtype:
+            gy = gy.to(y.dtype)
+        dx = dW = db = None
+        if ctx.needs_input_grad[0]:
+            dx = be.rowlinear_dgrad(gy, y, Wf, nseg, slope, x.dtype)
+        if ctx.needs_input_grad[1] or (b_dtype is not None and ctx.needs_input_grad[2]):
+            dW, db = be.rowlinear_wgrad(x, gy, y, nseg, slope, b_dtype is not None and ctx.needs_input_grad[2])
+            dW = dW.view(w_shape).to(w_dtype) if ctx.needs_input_grad[1] else None
+            if db is not None:
+                db = db.to(b_dtype)
+        return dx, dW, db, None, None, None
+
+
+# Off by default (round 3 measurement, tools/tune_rowlinear.py, hipGraph replay, MI355X): the hand-written kernels are
+# correct on every shape of the step (tests/test_mlp_gpu.py) but 1.2-5x SLOWER than the library GEMMs they would
+# replace -- 12288 x 128 -> 128 bf16: 44 us against 10 us forward, 148 against 40 us forward + backward; 8192 x 515 -> 256
+# in 4 segments: 597 against 32 us -- so the saved bias / activation / cast / partial-sum launches (~5 us each) do not
+# pay: the cfg2 step went from 13.5 to 21.7 ms with them on.  What they lack is known (480 live registers from the fully
+# unrolled k loop = one wave per SIMD; the weight re-staged per 64 rows); until that is fixed the library route stays.
+ROW_LINEAR = [False]
+
+
+def row_linear_supported(x, W, nseg=1):
+    """Can `row_linear` take this product?  fp32 / bf16 rows on the GPU, fp32 / bf16 weights, equal 64-row-aligned
+    segments."""
+    if not (ROW_LINEAR[0] and x.is_cuda and x.dtype in _DTYPE_CODE and W.dtype in (torch.float32, torch.bfloat16)):
+        return False
+    P = x.numel() // x.shape[-1] if x.numel() else 0
+    if P == 0 or not _lib.load().tpg_rowlinear_supported(int(x.shape[-1]), int(W.shape[-2]), 1):
+        return False
+    return nseg == 1 or (P % nseg == 0 and (P // nseg) % 64 == 0)
+
+
+def row_linear(x, W, bias=None, slope=1.0, nseg=1, out_dtype=None):
+    """x (..., Cin) rows (fp32 / bf16) -> lrelu_slope(x @ W^T + bias) (..., Cout) of `out_dtype` (default x.dtype).
+    W (Cout, Cin), or (nseg, Cout, Cin) with the leading rows in nseg equal blocks, block s using W[s].
+    slope 1.0 = no activation.  Reference: the 1x1 convolutions of gcn_lib/pointnet/gcn.py:96-147 and
+    discriminator.py:63-78 that are not inside a fused tail."""
+    _need(x.dtype in _DTYPE_CODE, f"row_linear supports fp32/bf16 rows, got {x.dtype}")
+    _need(0.0 <= float(slope) <= 1.0, "row_linear: LeakyReLU slope in [0, 1]")
+    lead = x.shape[:-1]
+    x2 = x.reshape(-1, x.shape[-1]).contiguous()
+    if x2.data_ptr() % 16:
+        x2 = x2.clone()                                    # (a row slice at an odd offset: the kernels take 16-byte rows)
+    _need((W.dim() == 2 and nseg == 1) or (W.dim() == 3 and W.shape[0] == nseg), "W (Cout,Cin) or (nseg,Cout,Cin)")
+    _need(W.shape[-1] == x2.shape[1], "row_linear: channel mismatch")
+    y = _RowLinear.apply(x2, W, bias, int(nseg), float(slope), out_dtype or x.dtype)
+    return y.view(*lead, W.shape[-2])
 
 
 # ---------------------------------------------------------------------- fused spectral norm

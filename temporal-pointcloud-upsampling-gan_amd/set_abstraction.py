@@ -410,7 +410,7 @@ class _PointnetSAModuleBase(nn.Module):
             if not grouper.use_xyz:
                 src = feat_rows.float()
             if isinstance(grouper, GroupAll):
-                return F.linear(src, W, conv.bias).unsqueeze(1)    # one group holding all N points
+                return rows_matmul(src, W, conv.bias).unsqueeze(1)   # one group holding all N points
             U = rows_matmul(src, W, conv.bias)                      # (B,N,C1)
             if idx is None:
                 idx = ops.ball_query(grouper.radius, grouper.nsample, xyz, new_xyz)
@@ -731,7 +731,7 @@ def _head_fp32(fc_layers, x):
         if not rows_first() or not isinstance(fc_layers, nn.Sequential):
             return fc_layers(x)                       # reference order: PyTorch's own hooks
         for m in fc_layers:
-            x = F.linear(x, sn_weight(m), m.bias) if isinstance(m, nn.Linear) else m(x)
+            x = rows_matmul(x, sn_weight(m), m.bias) if isinstance(m, nn.Linear) else m(x)
         return x
 
 

@@ -110,7 +110,7 @@ class BinaryMaskingModule(nn.Module):
         """(B,N,C) rows -> (B,N,1)."""
         for layer in self.upsample_layers:
             x = layer.forward_rows(x) if isinstance(layer, EdgeConv) else rows_seq(layer, x)
-        return torch.relu(rows_linear(self.decoder[1], rows_seq(self.decoder[0], x)))
+        return rows_linear(self.decoder[1], rows_seq(self.decoder[0], x), 0.0)      # ReLU = slope 0, in the epilogue
 
     def forward(self, feature):
         """Reference signature: (B,C,N,1) -> (B,N,1)."""

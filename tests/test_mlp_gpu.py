@@ -362,3 +362,83 @@ def test_idgcn_small_tails_equal_the_separate_launches(amp):
     assert _rel(res[0][0], res[1][0]) <= (3e-2 if amp else 1e-4)
     for a, b in zip(*res):
         assert a.shape == b.shape and _rel(a, b) <= (5e-2 if amp else 2e-3), _rel(a, b)
+
+
+# ------------------------------------------------------------------ row-wise linear layers (csrc/rowlinear.hip)
+@pytest.mark.parametrize("P,Cin,Cout,nseg", [
+    (12288, 3, 64, 1), (12288, 128, 128, 1), (12288, 128, 32, 1), (12288, 32, 16, 1), (12288, 96, 128, 1),
+    (12288, 256, 64, 1), (12288, 256, 12, 1), (12288, 12, 24, 1), (12288, 24, 24, 1), (12288, 64, 1, 1),
+    (65536, 6, 64, 2), (6144, 131, 128, 6), (4096, 259, 256, 2), (3072, 515, 256, 4), (8, 256, 256, 1),
+    (8, 64, 1, 1), (1, 5, 7, 1), (33, 17, 19, 1), (100, 300, 130, 1), (128, 16, 16, 2), (4096, 256, 256, 1), (2048, 515, 256, 1)])
+@pytest.mark.parametrize("din,dout", [("f32", "f32"), ("bf16", "bf16"), ("f32", "bf16")])
+def test_row_linear_against_pytorch_fp32(P, Cin, Cout, nseg, din, dout):
+    """tpg_rowlinear_fwd / dgrad / wgrad against plain PyTorch fp32 on the same (rounded) rows: the generator's and
+    the discriminators' channel counts (3, 6, 12, 24, 96, 131, 259, 515, ...), segments with their own weights,
+    bias and LeakyReLU in the epilogue, tiny P (the heads), ragged sizes.  fp32 in / out: 2e-5 of the output scale
+    (fp32 products, another summation order); bf16: one rounding of the stored values."""
+    import tpgan_amd.ops as ops
+    dt = {"f32": torch.float32, "bf16": torch.bfloat16}
+    torch.manual_seed(P + Cin + Cout)
+    dev = "cuda"
+    assert ops.ROW_LINEAR[0] is False           # (off by default: slower than the library, see ops.ROW_LINEAR; the op itself is tested)
+    x = torch.randn(P, Cin, device=dev).to(dt[din])
+    W = (torch.randn(nseg, Cout, Cin, device=dev) / Cin ** 0.5)
+    b = torch.randn(Cout, device=dev) * 0.3
+    gy = torch.randn(P, Cout, device=dev).to(dt[dout])
+    for slope, use_b in ((0.2, True), (1.0, False)):
+        xa = x.clone().requires_grad_(True)
+        Wa = (W if nseg > 1 else W[0]).clone().requires_grad_(True)
+        ba = b.clone().requires_grad_(True) if use_b else None
+        y = ops.row_linear(xa, Wa, ba, slope, nseg, dt[dout])
+        assert y.dtype == dt[dout] and y.shape == (P, Cout)
+        y.backward(gy)
+        # reference: fp32 math on the same inputs
+        xr = x.float().clone().requires_grad_(True)
+        Wr = W.clone().requires_grad_(True)
+        br = b.clone().requires_grad_(True) if use_b else None
+        z = torch.bmm(xr.view(nseg, P // nseg, Cin), Wr.transpose(1, 2)).view(P, Cout)
+        if use_b:
+            z = z + br
+        yr = torch.nn.functional.leaky_relu(z, slope) if slope != 1.0 else z
+        # the kernel's backward takes lrelu' from the sign of the STORED output
+        ys = y.detach().float()
+        gz = gy.float() * torch.where(ys > 0, torch.ones_like(ys), torch.full_like(ys, slope)) if slope != 1.0 else gy.float()
+        z.backward(gz)
+        tol_y = 2e-5 if dout == "f32" else 8e-3
+        assert float((y.float() - yr).abs().max()) <= tol_y * max(1.0, float(yr.abs().max())), (slope, float((y.float() - yr).abs().max()))
+        tol_g = 2e-5 if din == "f32" else 8e-3
+        assert float((xa.grad.float() - xr.grad).abs().max()) <= tol_g * max(1.0, float(xr.grad.abs().max()))
+        gW = Wa.grad.view(nseg, Cout, Cin)
+        assert float((gW - Wr.grad).abs().max()) <= 1e-4 * max(1.0, float(Wr.grad.abs().max())), float((gW - Wr.grad).abs().max())
+        if use_b:
+            assert float((ba.grad - br.grad).abs().max()) <= 1e-4 * max(1.0, float(br.grad.abs().max()))
+
+
+def test_row_linear_declines_what_it_cannot_stage():
+    """Channel counts whose 16-row chunk does not fit the weight-gradient kernel's LDS are reported unsupported (the
+    host layer then keeps the library GEMM) instead of failing inside a launch."""
+    import tpgan_amd.ops as ops
+    x = torch.randn(256, 515, device="cuda")
+    prev, ops.ROW_LINEAR[0] = ops.ROW_LINEAR[0], True
+    try:
+        assert ops.row_linear_supported(x, torch.randn(256, 515, device="cuda"))
+        assert not ops.row_linear_supported(x, torch.randn(512, 515, device="cuda"))
+        assert not ops.row_linear_supported(torch.randn(256, 2000, device="cuda"), torch.randn(64, 2000, device="cuda"))
+    finally:
+        ops.ROW_LINEAR[0] = prev
+
+
+def test_row_linear_is_bitwise_reproducible():
+    import tpgan_amd.ops as ops
+    torch.manual_seed(1)
+    x = torch.randn(12288, 96, device="cuda")
+    W = torch.randn(128, 96, device="cuda").requires_grad_(True)
+    b = torch.randn(128, device="cuda").requires_grad_(True)
+    gy = torch.randn(12288, 128, device="cuda")
+    res = []
+    for _ in range(2):
+        xa = x.clone().requires_grad_(True)
+        y = ops.row_linear(xa, W, b, 0.2)
+        res.append((y.detach().clone(),) + tuple(g.clone() for g in torch.autograd.grad(y, [xa, W, b], gy)))
+    for a, c in zip(*res):
+        assert torch.equal(a, c)

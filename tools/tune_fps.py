@@ -10,11 +10,15 @@ import sys
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 CSRC = os.path.join(ROOT, "temporal-pointcloud-upsampling-gan_amd", "csrc")
 VDIR = os.path.join(CSRC, "variants")
-VARIANTS = {"default": {},
-            "wide": {"TPG_FPS_1024_BLOCK": 256, "TPG_FPS_2048_BLOCK": 512, "TPG_FPS_4096_BLOCK": 1024, "TPG_FPS_8192_BLOCK": 1024},
-            "mid": {"TPG_FPS_1024_BLOCK": 128, "TPG_FPS_2048_BLOCK": 256, "TPG_FPS_4096_BLOCK": 512, "TPG_FPS_8192_BLOCK": 1024},
-            "narrow": {"TPG_FPS_1024_BLOCK": 64, "TPG_FPS_2048_BLOCK": 128, "TPG_FPS_4096_BLOCK": 256, "TPG_FPS_8192_BLOCK": 512}}
-SHAPES = [(24, 4096, 1024), (24, 1024, 256), (8, 1024, 512), (8, 2048, 512), (8, 8192, 1024), (8, 512, 128)]
+NOSLP = ["-fno-slp-vectorize"]
+VARIANTS = {"default": {"_flags": NOSLP},
+            "poll": {"_flags": NOSLP, "TPG_FPS_POLL_EXCHANGE": 1},
+            "slp_poll": {"TPG_FPS_POLL_EXCHANGE": 1},
+            "slp_barrier": {},          # the round-2 kernel (wrong picks on some hosts, see build.py)
+            "w512": {"_flags": NOSLP, "TPG_FPS_4096_BLOCK": 512},
+            "w1024": {"_flags": NOSLP, "TPG_FPS_4096_BLOCK": 1024, "TPG_FPS_2048_BLOCK": 512, "TPG_FPS_1024_BLOCK": 256},
+            "narrow": {"_flags": NOSLP, "TPG_FPS_1024_BLOCK": 64, "TPG_FPS_2048_BLOCK": 128, "TPG_FPS_4096_BLOCK": 256, "TPG_FPS_8192_BLOCK": 512}}
+SHAPES = [(24, 4096, 1024), (24, 1024, 256), (8, 1024, 512), (8, 2048, 512), (8, 8192, 1024), (8, 512, 128), (20, 16384, 1024)]
 
 
 def build():
@@ -23,7 +27,8 @@ def build():
         out = os.path.join(VDIR, f"fps_{tag}.so")
         subprocess.check_call(["/opt/rocm/bin/hipcc", "-O3", "--offload-arch=gfx950", "-ffp-contract=off", "-std=c++17",
                                "-fPIC", "-shared", "-I", os.path.join(ROOT, "include")] +
-                              [f"-D{k}={v}" for k, v in defs.items()] + [os.path.join(CSRC, "fps.hip"), "-o", out])
+                              defs.get("_flags", []) + [f"-D{k}={v}" for k, v in defs.items() if k != "_flags"] +
+                              [os.path.join(CSRC, "fps.hip"), "-o", out])
         print("built", out)
 
 
