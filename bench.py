@@ -1,7 +1,7 @@
 """Headline benchmark: GAN train-steps/s (full G+D adversarial step) on synthetic
 4096-point x 3-frame fluid clips, batch 8 per GPU (BASELINE.json configs[1]; weak scaling).
 
-    python bench.py --gpus 1 --steps 20 --warmup 3
+    python bench.py --gpus 1 --steps 200 --warmup 5
     python bench.py --config cfg4 | cfg5shard        # the other single-GPU workloads of BASELINE.json
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 \
         --master-port P bench.py --gpus N --steps K --warmup W
@@ -17,8 +17,9 @@ Extra legs (rank 0, N == 1 only):
                 kernel, `mfma` the matrix-core work (hand-written MFMA kernels and the remaining
                 library GEMMs: flops / time against the 2.5 PFLOP/s dense bf16 peak);
   cpu_baseline  the same step function on the host cores through the oracle ops (kind
-                "port": the reference has no CPU path for pointnet2_ops/FRNN), on a bounded
-                sample (4 clips instead of 8), scaled to the metric's unit.
+                "port": the reference has no CPU path for pointnet2_ops/FRNN), BASELINE.md section 3's
+                protocol -- 2 warm-up steps + 5 timed steps, median -- on a bounded sample (2 clips per
+                step instead of 8), scaled to the metric's unit.
 """
 import argparse
 import json
@@ -74,8 +75,10 @@ def run_steps(models, clips, n, sync, amp_dtype, start=0):
     return out
 
 
-def cpu_baseline(sample_batch, per_gpu_batch, n_hi):
-    """Time ONE step of the same workload on the host cores (oracle ops + CPU PyTorch)."""
+def cpu_baseline(sample_batch, per_gpu_batch, n_hi, warm=2, timed=5):
+    """the same workload's step on the host cores (oracle ops + CPU PyTorch), 2 warm-up steps +
+    5 timed steps, median; `sample_batch` clips per step (the batch that keeps the leg to about a minute), scaled to
+    the batch-`per_gpu_batch` step."""
     # threads = the cores this process may actually run on (a GPU box hands each job a share)
     cores = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
     cores = max(1, min(cores, int(os.environ.get("TPGAN_CPU_THREADS", "16"))))
@@ -86,20 +89,29 @@ def cpu_baseline(sample_batch, per_gpu_batch, n_hi):
         torch.set_num_threads(cores)
         np.random.seed(0)
         models = build("cpu")
-        spec = configs.SPECS[CONFIG]
-        warm = [configs.make_clip(CONFIG, batch=2, points=512 if spec["kind"] == "fluid" else 1024, seed=7)]
-        run_steps(models, warm, 1, None, None)                      # page in / thread pools
-        clips = [configs.make_clip(CONFIG, batch=sample_batch, points=n_hi, seed=1234)]
-        t0 = time.perf_counter()
-        run_steps(models, clips, 1, None, None)
-        dt = time.perf_counter() - t0
+        clips = [configs.make_clip(CONFIG, batch=sample_batch, points=n_hi, seed=1234 + i) for i in range(2)]
+        times = []
+        for i in range(warm + timed):
+            t0 = time.perf_counter()
+            run_steps(models, clips, 1, None, None, start=i)
+            dt = time.perf_counter() - t0
+            if i >= warm:
+                times.append(dt)
+            log(f"cpu baseline step {i + 1}/{warm + timed}: {dt:.2f} s{'' if i >= warm else ' (warm-up)'}")
+        med = float(np.median(times))
     finally:
         torch_backend.uninstall()
-    return {"value": (sample_batch / per_gpu_batch) / dt, "unit": "steps/s", "cores": cores,
-            "kind": "port",
-            "sample": f"1 full G+D step on {sample_batch} clips of {n_hi} pts x{configs.SPECS[CONFIG]['frames']} frames "
-                      f"({dt:.1f} s), scaled by {sample_batch}/{per_gpu_batch} to the batch-"
-                      f"{per_gpu_batch} step; fp32; oracle C ops (OpenMP) + CPU PyTorch convs"}
+    try:
+        with open("/proc/cpuinfo") as fh:
+            model = next((l.split(":", 1)[1].strip() for l in fh if l.startswith("model name")), "unknown")
+    except OSError:
+        model = "unknown"
+    return {"value": (sample_batch / per_gpu_batch) / med, "unit": "steps/s", "cores": cores,
+            "kind": "port", "cpu": model,
+            "sample": f"{warm} warm-up + {timed} timed full G+D steps on {sample_batch} clips of {n_hi} pts x"
+                      f"{configs.SPECS[CONFIG]['frames']} frames, median {med:.2f} s per step (min {min(times):.2f}, max "
+                      f"{max(times):.2f}), scaled by {sample_batch}/{per_gpu_batch} to the batch-{per_gpu_batch} step; fp32; "
+                      f"oracle C ops (OpenMP, {cores} threads) + CPU PyTorch convs"}
 
 
 def roofline_leg(models, clips, steps, sync, amp_dtype):
@@ -156,6 +168,18 @@ def roofline_leg(models, clips, steps, sync, amp_dtype):
                             "0.57 us/round at 4096 points); hidden on the index-plan streams in graph mode")
         roofline["us_per_round"] = round(summ["fps"]["avg_us"] / max(1, spec["points"] // 4 - 1), 4)
     line = {"roofline": roofline}
+    # north_star's own target: HBM utilisation of ball_query + group (here: the row gather that replaces
+    # grouping_operation + first conv, csrc/rowgather.hip) -- algorithmic bytes of both over the time of both
+    bq = [k for k in ("ball_query", "rowcombine_fwd") if k in summ]
+    if len(bq) == 2:
+        nbytes = sum(summ[k]["bytes_per_launch"] * summ[k]["launches"] for k in bq)
+        us = sum(summ[k]["total_ms"] for k in bq) * 1e3
+        line["ball_query_plus_group"] = {
+            "bytes_per_step": int(nbytes / steps_f), "us_per_step": round(us / steps_f, 2),
+            "achieved_GBps": round(nbytes / us / 1e3, 1), "frac": round(nbytes / us / 1e3 / HBM_PEAK_GBPS, 4),
+            "parts": {k: {"launches_per_step": summ[k]["launches"] / steps_f, "avg_us": round(summ[k]["avg_us"], 2),
+                          "GBps": round(summ[k]["gbps"], 1)} for k in bq},
+            "note": "HIP events around each launch of the eagerly launched step body; target of BASELINE.json: 0.40"}
     if streaming:
         sdom = max(streaming, key=lambda k: summ[k]["total_ms"])
         line["roofline_streaming"] = roof(sdom, "largest total time among the HBM-streaming hand-written kernels")
@@ -177,7 +201,8 @@ def roofline_leg(models, clips, steps, sync, amp_dtype):
             # (20+ us of host time per call): the kernel time comes from the committed rocprofv3 summary
             mf[grp] = {"kernels": names, "tflop_per_step": round(fl / steps_f / 1e12, 4),
                        "launches_per_step": sum(summ[k]["launches"] for k in names) / steps_f,
-                       "ms_per_step": lib_ms, "ms_source": "profiles/%s (Cijk_* rows / %d executions)" % (STATS_FILE % CONFIG, STATS_EXECUTIONS),
+                       "ms_per_step": lib_ms, "ms_source": "profiles/%s (Cijk_* rows / executions of %s; null when the "
+                                                             "summaries were made from other sources)" % (STATS_FILE % CONFIG, META_FILE),
                        "achieved_tflops": round(fl / steps_f / 1e12 / (lib_ms / 1e3), 2) if lib_ms else None,
                        "frac_of_peak": round(fl / steps_f / 1e12 / (lib_ms / 1e3) / MFMA_PEAK_TFLOPS, 5)
                        if lib_ms else None}
@@ -202,19 +227,49 @@ def roofline_leg(models, clips, steps, sync, amp_dtype):
     return line, table
 
 
-PMC_FILE = "r02_pmc_traffic.json"
-STATS_FILE = "r02_final_%s_graph_bf16_kernel_stats.csv"      # % config
-STATS_EXECUTIONS = 15      # `bench.py --config X --steps 10 --warmup 2 --no-extra`: 3 while capturing + 2 + 10
+PMC_FILE = "r03_pmc_traffic.json"
+STATS_FILE = "r03_final_%s_graph_bf16_kernel_stats.csv"      # % config
+META_FILE = "r03_final_meta.json"       # written by tools/refresh_profiles.sh next to the summaries it describes
+
+
+def source_fingerprint():
+    """sha256 over the sources a kernel summary depends on (the library's csrc/, the package's Python, bench.py):
+    tools/refresh_profiles.sh stores it next to the summaries, and figures read from them are reported only while it
+    still matches (a code change must not leave stale profile numbers in the bench line)."""
+    import glob
+    import hashlib
+    pkg = os.path.join(ROOT, "temporal-pointcloud-upsampling-gan_amd")
+    files = sorted(glob.glob(os.path.join(pkg, "csrc", "*.h*")) + glob.glob(os.path.join(pkg, "*.py"))
+                   + glob.glob(os.path.join(ROOT, "include", "*.h")) + [os.path.join(ROOT, "bench.py")])
+    h = hashlib.sha256()
+    for f in files:
+        with open(f, "rb") as fh:
+            h.update(os.path.basename(f).encode() + b"\0" + fh.read())
+    return h.hexdigest()[:16]
+
+
+def _profile_meta():
+    """{"executions": step executions per profiled process, "source": fingerprint} of the committed summaries, or None
+    when absent / made from other sources than the ones running now."""
+    try:
+        with open(os.path.join(ROOT, "profiles", META_FILE)) as fh:
+            meta = json.load(fh)
+        return meta if meta.get("source") == source_fingerprint() and meta.get("executions") else None
+    except (OSError, ValueError):
+        return None
 
 
 def _library_gemm_ms(config):
-    """hipBLASLt kernel time per step from the committed rocprofv3 summary of this config, or None when the
-    file is not there."""
+    """hipBLASLt kernel time per step from the committed rocprofv3 summary of this config, or None when the file is
+    not there or was made from another state of the sources."""
     import csv
+    meta = _profile_meta()
+    if meta is None:
+        return None
     try:
         with open(os.path.join(ROOT, "profiles", STATS_FILE % config)) as fh:
             tot = sum(float(r["TotalDurationNs"]) for r in csv.DictReader(fh) if r["Name"].startswith("Cijk"))
-        return round(tot / 1e6 / STATS_EXECUTIONS, 4)
+        return round(tot / 1e6 / int(meta["executions"]), 4)
     except (OSError, KeyError, ValueError):
         return None
 
@@ -222,8 +277,8 @@ def _library_gemm_ms(config):
 def pmc_traffic(kernel):
     """HBM bytes per launch of `kernel` from the committed rocprofv3 PMC passes (profiles/), with the
     gfx950 FETCH_SIZE x2 correction for wide coalesced reads; None when no PMC file is present."""
-    if CONFIG != "cfg2":
-        return None                      # the committed PMC passes are of the cfg2 step body
+    if CONFIG != "cfg2" or _profile_meta() is None:
+        return None                      # the committed PMC passes are of the cfg2 step body, at a known source state
     path = os.path.join(ROOT, "profiles", PMC_FILE)
     try:
         with open(path) as fh:
@@ -236,15 +291,16 @@ def pmc_traffic(kernel):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=20)
-    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--steps", type=int, default=200)        # >= 2 s timed region at cfg2
+    ap.add_argument("--warmup", type=int, default=5)
     ap.add_argument("--config", choices=sorted(configs.SPECS), default="cfg2",
                     help="BASELINE.json workload (cfg2 = the headline metric; cfg3 is cfg2 on 8 ranks)")
     ap.add_argument("--batch", type=int, default=None, help="clips per GPU (default: the workload's, 8)")
     ap.add_argument("--points", type=int, default=None, help="high-res points per frame (default: the workload's)")
     ap.add_argument("--dtype", choices=["bf16", "fp32"], default="bf16")
     ap.add_argument("--no-extra", action="store_true", help="skip roofline and cpu_baseline legs")
-    ap.add_argument("--cpu-sample-batch", type=int, default=4)
+    ap.add_argument("--cpu-sample-batch", type=int, default=2,
+                    help="clips per CPU-baseline step (7 steps are run: 2 warm-up + 5 timed)")
     ap.add_argument("--no-graph", action="store_true",
                     help="run the step eagerly instead of replaying it from captured hipGraphs")
     ap.add_argument("--eager-body", action="store_true",
@@ -336,9 +392,9 @@ def main():
                    "value_definition": "batch-of-%d steps per second summed over ranks" % args.batch,
                    "precision": "bf16 autocast on 1x1 convs/linears; coordinates, neighbour search, "
                                 "indices, Chamfer in fp32" if args.dtype == "bf16" else "fp32",
-                   "parity": "indices bit-exact vs oracle; fp32 model outputs vs reference goldens 1e-5 (CPU) / 2e-4 "
-                             "(GPU: GEMM summation order through ~20 layers); the bf16 replayed step vs the fp32 eager "
-                             "step: tests/test_graph_gpu.py::test_bf16_graph_against_fp32_eager_at_bench_size",
+                   "parity": "asserted by tests/ (-m gpu), not restated here: kernels bit-exact vs oracle/tpgref.c, models vs "
+                             "the reference goldens, replay bitwise == its body, bf16 vs fp32 conditioned "
+                             "(tests/test_graph_gpu.py)",
                    "parallelism": f"dp{world}", "step_mode": mode, "last_losses": last},
     }
     if world > 1 and GRAPHED is not None and getattr(GRAPHED, "timing", None):

@@ -30,6 +30,12 @@ namespace {
 
 enum { MODE_GATHER = 0, MODE_SUB = 1, MODE_EDGE = 2 };
 
+typedef unsigned int rc_u32x4 __attribute__((ext_vector_type(4)));
+typedef float rc_f32x4 __attribute__((ext_vector_type(4)));
+#ifndef TPG_RC_NT_STORE
+#define TPG_RC_NT_STORE 0        // 1: the forward's output rows leave with non-temporal stores (tools/tune_rowcombine.py)
+#endif
+
 // NE consecutive elements of T <-> NE floats (16-byte vector accesses).
 template <typename T, int NE> struct RowIO;
 template <int NE> struct RowIO<float, NE> {
@@ -44,6 +50,13 @@ template <int NE> struct RowIO<float, NE> {
 #pragma unroll
         for (int i = 0; i < NE / 4; ++i)
             reinterpret_cast<float4 *>(p)[i] = make_float4(v[4 * i], v[4 * i + 1], v[4 * i + 2], v[4 * i + 3]);
+    }
+    static __device__ __forceinline__ void store_stream(float *p, const float (&v)[NE]) {
+#pragma unroll
+        for (int i = 0; i < NE / 4; ++i) {
+            const rc_f32x4 w = {v[4 * i], v[4 * i + 1], v[4 * i + 2], v[4 * i + 3]};
+            __builtin_nontemporal_store(w, reinterpret_cast<rc_f32x4 *>(p) + i);
+        }
     }
 };
 template <> struct RowIO<__hip_bfloat16, 8> {
@@ -66,6 +79,18 @@ template <> struct RowIO<__hip_bfloat16, 8> {
                    ((unsigned)(*reinterpret_cast<const unsigned short *>(&hi)) << 16);
         }
         *reinterpret_cast<uint4 *>(p) = make_uint4(w[0], w[1], w[2], w[3]);
+    }
+    static __device__ __forceinline__ void store_stream(__hip_bfloat16 *p, const float (&v)[8]) {
+        unsigned w[4];
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const __hip_bfloat16 lo = __float2bfloat16(v[2 * i]);
+            const __hip_bfloat16 hi = __float2bfloat16(v[2 * i + 1]);
+            w[i] = (unsigned)(*reinterpret_cast<const unsigned short *>(&lo)) |
+                   ((unsigned)(*reinterpret_cast<const unsigned short *>(&hi)) << 16);
+        }
+        const rc_u32x4 x = {w[0], w[1], w[2], w[3]};
+        __builtin_nontemporal_store(x, reinterpret_cast<rc_u32x4 *>(p));
     }
 };
 // elements per thread: 8 as soon as one side is bf16 (16-byte bf16 vectors), else 4
@@ -132,7 +157,8 @@ __global__ __launch_bounds__(256) void rowcombine_fwd_kernel(
                 u[i] = u[i] + (d > 0.0f ? d : d * slope);
             }
         }
-        Out::store(out + (size_t)row * C + col, u);
+        if (TPG_RC_NT_STORE) Out::store_stream(out + (size_t)row * C + col, u);
+        else Out::store(out + (size_t)row * C + col, u);
     };
     for (; (unsigned long long)t + (unsigned long long)(UF - 1) * stride < total; t += UF * stride) {
         unsigned row[UF], col[UF], bs[UF], b[UF];
@@ -166,7 +192,8 @@ __global__ __launch_bounds__(256) void rowcombine_fwd_kernel(
                     u[j][i] = u[j][i] + (d > 0.0f ? d : d * slope);
                 }
             }
-            Out::store(out + (size_t)row[j] * C + col[j], u[j]);
+            if (TPG_RC_NT_STORE) Out::store_stream(out + (size_t)row[j] * C + col[j], u[j]);
+            else Out::store(out + (size_t)row[j] * C + col[j], u[j]);
         }
     }
     for (; t < total; t += stride) one(t);

@@ -1013,24 +1013,36 @@ ROW_GATHER, ROW_SUB, ROW_EDGE = 0, 1, 2
 # holds (dx0, qneg, K) of the LAST tail backward -- a strong reference, so dx0's memory cannot have been handed to
 # another tensor while the slot is full, and "same pointer, size and type" means "these very rows".  A gradient that
 # was accumulated with another (a new tensor) or anything else simply does not match and takes the ordinary path.
-_ROWSUM_SLOT = [None]
+# One slot PER DEVICE (autograd runs one backward thread per device, two devices must not race on a shared
+# slot), and an offer REPLACES whatever an earlier tail left behind (a tail whose input did not come from a ROW_SUB
+# gather never has its offer taken: the next tail's offer, or the next gather's look, drops it).
+class _RowsumSlots(dict):
+    """device index -> (dx0, qneg, K); `slots[0]` reads / clears EVERY device's slot (tests, the A/B switch)."""
+
+    def __getitem__(self, key):
+        if key == 0 and 0 not in self:
+            return next((v for v in self.values() if v is not None), None)
+        return dict.get(self, key)
+
+
+_ROWSUM_SLOT = _RowsumSlots()
 _ROWSUM_HANDOFF = [os.environ.get("TPG_ROWSUM_HANDOFF", "1") != "0"]
 
 
 def set_rowsum_handoff(flag):
     """A/B and test switch for the hand-off above; returns the previous setting."""
     prev, _ROWSUM_HANDOFF[0] = _ROWSUM_HANDOFF[0], bool(flag)
-    _ROWSUM_SLOT[0] = None
+    _ROWSUM_SLOT.clear()
     return prev
 
 
 def _offer_rowsum(dx0, qneg, K):
-    _ROWSUM_SLOT[0] = (dx0, qneg, K)
+    _ROWSUM_SLOT[("dev", dx0.device.index)] = (dx0, qneg, K)
 
 
 def _take_rowsum(gout):
-    """qneg if gout (B,S,K,C) is the dx0 of the slot, else None; empties the slot either way."""
-    slot, _ROWSUM_SLOT[0] = _ROWSUM_SLOT[0], None
+    """qneg if gout (B,S,K,C) is the dx0 of its device's slot, else None; empties that slot either way."""
+    slot = _ROWSUM_SLOT.pop(("dev", gout.device.index), None)
     if slot is None:
         return None
     dx0, qneg, K = slot
