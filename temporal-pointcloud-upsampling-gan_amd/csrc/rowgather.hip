@@ -33,7 +33,10 @@ enum { MODE_GATHER = 0, MODE_SUB = 1, MODE_EDGE = 2 };
 typedef unsigned int rc_u32x4 __attribute__((ext_vector_type(4)));
 typedef float rc_f32x4 __attribute__((ext_vector_type(4)));
 #ifndef TPG_RC_NT_STORE
-#define TPG_RC_NT_STORE 0        // 1: the forward's output rows leave with non-temporal stores (tools/tune_rowcombine.py)
+#define TPG_RC_NT_STORE 0        // 1: non-temporal stores for the forward's output rows.  Round 3: with two chains per thread
+                                 // 46.7 -> 20.8 us ALONE on cache-resident operands (tools/tune_rowcombine.py), but in the
+                                 // step 24.0 instead of 19.2 us per launch and +5 % step time (tools/ab_rowcombine.sh): the
+                                 // consumer reads these rows next and wants them in L2.  Off.
 #endif
 
 // NE consecutive elements of T <-> NE floats (16-byte vector accesses).
