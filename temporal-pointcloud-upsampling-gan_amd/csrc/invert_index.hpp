@@ -133,19 +133,29 @@ __global__ __launch_bounds__(kThreads) void invert_index_kernel(const IdxT *__re
     if (use_cnt)
         for (int n = tid; n < N; n += kThreads) cnt[n] = 0;
     __syncthreads();
-    for (int base = e_lo; base < e_hi; base += 64 * kUnroll) {
-        int d[kUnroll];
+    {
+        // (the next group's loads are in flight while this group's counters are bumped)
+        int d[kUnroll], dn[kUnroll];
 #pragma unroll
         for (int u = 0; u < kUnroll; ++u) {
-            const int i = base + u * 64 + lane;
+            const int i = e_lo + u * 64 + lane;
             d[u] = i < e_hi ? dest_of(id, i, N) : -1;
         }
+        for (int base = e_lo; base < e_hi; base += 64 * kUnroll) {
 #pragma unroll
-        for (int u = 0; u < kUnroll; ++u)
-            if (d[u] >= 0) {
-                atomicAdd((int *)&hist0[(d[u] & dmask) * kWaves + wave], 1);
-                if (use_cnt) atomicAdd(&cnt[d[u]], 1);
+            for (int u = 0; u < kUnroll; ++u) {
+                const int i = base + 64 * kUnroll + u * 64 + lane;
+                dn[u] = i < e_hi ? dest_of(id, i, N) : -1;
             }
+#pragma unroll
+            for (int u = 0; u < kUnroll; ++u)
+                if (d[u] >= 0) {
+                    atomicAdd((int *)&hist0[(d[u] & dmask) * kWaves + wave], 1);
+                    if (use_cnt) atomicAdd(&cnt[d[u]], 1);
+                }
+#pragma unroll
+            for (int u = 0; u < kUnroll; ++u) d[u] = dn[u];
+        }
     }
     __syncthreads();
     if (use_cnt) {
@@ -168,12 +178,20 @@ __global__ __launch_bounds__(kThreads) void invert_index_kernel(const IdxT *__re
             __syncthreads();
         }
         const int dshift = p ? (p - 1) * bits : 0;       // of kh, for this pass's digit (p > 0)
+        int raw[kUnroll], rawn[kUnroll];
+#pragma unroll
+        for (int u = 0; u < kUnroll; ++u) {
+            const int i = e_lo + u * 64 + lane;
+            raw[u] = i < e_hi ? (src ? src[i] : i) : 0;
+        }
         for (int base = e_lo; base < e_hi; base += 64 * kUnroll) {
-            int raw[kUnroll], ev[kUnroll], dg[kUnroll], kh[kUnroll];
+            int ev[kUnroll], dg[kUnroll], kh[kUnroll];
+            // (prefetch: the next group's words are in flight while this group is ranked and scattered; they were
+            // written by the PREVIOUS pass -- before its closing barrier -- so reading them early is safe)
 #pragma unroll
             for (int u = 0; u < kUnroll; ++u) {
-                const int i = base + u * 64 + lane;
-                raw[u] = i < e_hi ? (src ? src[i] : i) : 0;
+                const int i = base + 64 * kUnroll + u * 64 + lane;
+                rawn[u] = i < e_hi ? (src ? src[i] : i) : 0;
             }
 #pragma unroll
             for (int u = 0; u < kUnroll; ++u) {
@@ -214,6 +232,8 @@ __global__ __launch_bounds__(kThreads) void invert_index_kernel(const IdxT *__re
                     if (rank == group - 1) cur[slot] = pos + 1;          //  ... before its last lane advances the cursor)
                 }
             }
+#pragma unroll
+            for (int u = 0; u < kUnroll; ++u) raw[u] = rawn[u];
         }
         __syncthreads();            // dst complete and visible to the whole workgroup
     }
