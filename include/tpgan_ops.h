@@ -375,7 +375,7 @@ int tpg_small_tail_bwd(const void *h, const void *out, const void *gout, const u
  * (discriminator.py:503-516,598-612) -- in the reference: cuDNN / cuBLAS calls plus separate bias / activation kernels.
  *     y[p, o] = lrelu_slope( sum_c x[p, c] * W[seg(p)][o, c] + bias[o] )
  * x (P, Cin) and y (P, Cout) channels-last rows, f32 or bf16 (tpg_dtype); W (nseg, Cout, Cin) f32: nseg equal
- * consecutive row blocks with their own weights (P % nseg == 0, and (P / nseg) % 64 == 0 when nseg > 1;
+ * consecutive row blocks with their own weights (P % nseg == 0, and (P / nseg) % 128 == 0 when nseg > 1;
  * Cin, Cout <= 1000: tpg_rowlinear_supported);
  * bias (Cout) f32 or NULL; slope in [0, 1], 1 = no activation.  fp32 products and accumulation on
  * v_mfma_f32_16x16x4_f32.  x, y, W 16-byte aligned.

@@ -80,12 +80,11 @@ __device__ __forceinline__ void rl_load_r4(const T *M, long long k, long long Kr
 //   BT == false (forward): KA = Cin,  N = Cout, B[n][k] = W[n][k]   (straight copy)
 //   BT == true  (dgrad)  : KA = Cout, N = Cin,  B[n][k] = W[k][n]   (transposed while staging: the compute loop is the
 //                          forward's);  Y (P, KA) = the forward's output, slope_in its slope
-// A workgroup (4 waves x 16 rows) stages B once per pass with coalesced loads -- ONE L2 round trip instead of one per
-// 16 k's -- and every wave then streams its A fragments (<= 256 k's in registers, loaded in one go) against
-// ds_read_b128 fragments of B.  Rows of B are KS = roundup16(KA) + 4 floats apart: the 16 lanes of a k-slot read
+// A workgroup (8 waves x 16 rows) stages B once per pass with coalesced loads -- ONE L2 round trip instead of one per
+// 16 k's -- and every wave then streams its A fragments (one 16-byte load per 16 k's, the next one in flight) against
+// ds_read_b128 fragments of B in a rolled loop.  Rows of B are KS = roundup16(KA) + 4 floats apart: the 16 lanes of a k-slot read
 // 16-byte words 4 banks apart, conflict-free.
 constexpr int RL_NP_MAX = 128;       // output columns per pass (8 tiles of 16: 32 accumulator registers)
-constexpr int RL_KB = 256;           // k's whose A fragments a wave holds at once (16 x 16 bytes per lane)
 constexpr int RL_LDS_FLOATS = 16000; // 64 KB of dynamic LDS minus slack
 
 __host__ __device__ inline int rl_ks(int KA) { return ((KA + 15) & ~15) + 4; }
@@ -96,19 +95,23 @@ __host__ __device__ inline int rl_np(int KA, int N) {
     return np < n16 ? np : n16;
 }
 
+constexpr int RL_WAVES = 8;                       // waves per workgroup: 8 x 16 = 128 rows share one staging of the weight
+constexpr int RL_THREADS = RL_WAVES * 64;
+constexpr int RL_WG_ROWS = RL_WAVES * 16;
+
 template <typename TA, typename TO, bool BT>
-__global__ __launch_bounds__(256) void rowlin_kernel(const TA *__restrict__ A, const TA *__restrict__ Y,
-                                                     const float *__restrict__ W, const float *__restrict__ bias,
-                                                     TO *__restrict__ out, long long P, long long Pseg, int Cin, int Cout,
-                                                     float slope_in, float slope_out) {
+__global__ __launch_bounds__(RL_THREADS) void rowlin_kernel(const TA *__restrict__ A, const TA *__restrict__ Y,
+                                                            const float *__restrict__ W, const float *__restrict__ bias,
+                                                            TO *__restrict__ out, long long P, long long Pseg, int Cin,
+                                                            int Cout, float slope_in, float slope_out) {
     extern __shared__ __attribute__((aligned(16))) float rl_lds[];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int r = lane & 15, g = lane >> 4;
-    const long long wg0 = (long long)blockIdx.x * 64;                 // first row of the workgroup
+    const long long wg0 = (long long)blockIdx.x * RL_WG_ROWS;         // first row of the workgroup
     const long long r0 = wg0 + wave * 16;
     const int KA = BT ? Cout : Cin, N = BT ? Cin : Cout;
     const int KS = rl_ks(KA), NP = rl_np(KA, N), K16 = (KA + 15) & ~15;
-    const float *Ws = W + (wg0 / Pseg) * (long long)Cout * Cin;       // (a workgroup never straddles segments: Pseg % 64 == 0)
+    const float *Ws = W + (wg0 / Pseg) * (long long)Cout * Cin;       // (a workgroup never straddles segments)
     const bool vecA = (KA & 3) == 0;
     const long long row = r0 + r;
     const bool rok = row < P;
@@ -117,10 +120,10 @@ __global__ __launch_bounds__(256) void rowlin_kernel(const TA *__restrict__ A, c
         const int nt = (ncur + 15) >> 4;
         __syncthreads();                                              // (the previous pass is done with the LDS)
         if (!BT) {
-            // B[nn][k] = W[n0 + nn][k]: 16 threads x 16 bytes walk a row, 16 rows at a time (no divisions)
+            // B[nn][k] = W[n0 + nn][k]: 16 threads x 16 bytes walk a row, 32 rows at a time (no divisions)
             const int tr = tid >> 4, tk = (tid & 15) * 4;
             const bool vecW = (Cin & 3) == 0;
-            for (int nn = tr; nn < nt * 16; nn += 16) {
+            for (int nn = tr; nn < nt * 16; nn += RL_THREADS / 16) {
                 const float *src = Ws + (long long)(n0 + nn) * Cin;
                 for (int k = tk; k < K16; k += 64) {
                     float4 v = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
@@ -141,7 +144,7 @@ __global__ __launch_bounds__(256) void rowlin_kernel(const TA *__restrict__ A, c
             // B[nn][k] = W[k][n0 + nn]: 16 threads x 16 bytes walk a row k of W along nn (coalesced), transposed stores
             const int tk = tid >> 4, tn = (tid & 15) * 4;
             const bool vecW = (Cin & 3) == 0 && (n0 & 3) == 0;
-            for (int k = tk; k < K16; k += 16) {
+            for (int k = tk; k < K16; k += RL_THREADS / 16) {
                 const float *src = Ws + (long long)k * Cin + n0;
                 for (int nn = tn; nn < nt * 16; nn += 64) {
                     float4 v = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
@@ -167,39 +170,38 @@ __global__ __launch_bounds__(256) void rowlin_kernel(const TA *__restrict__ A, c
         f4 acc[RL_NP_MAX / 16];
 #pragma unroll
         for (int c = 0; c < RL_NP_MAX / 16; ++c) acc[c] = f4{0.0f, 0.0f, 0.0f, 0.0f};
-        for (int kb = 0; kb < KA; kb += RL_KB) {
-            // every A fragment of this k block in one go: lane (r, g) holds x[row][k0 + 4g .. + 3] of each 16-k chunk
-            float a[RL_KB / 16][4];
+        // software-pipelined k loop (NOT unrolled: ~90 live registers, several waves per SIMD): the A fragment of the
+        // next 16 k's is in flight while this one meets its <= 8 B fragments
+        float a[4], an[4];
+        rl_load_k4(A, row, rok, KA, 4 * g, vecA, a);
+        if (Y != nullptr) {                                           // gz = gy * lrelu'(z): sign(y) == sign(z)
+            float yv[4];
+            rl_load_k4(Y, row, rok, KA, 4 * g, vecA, yv);
 #pragma unroll
-            for (int q = 0; q < RL_KB / 16; ++q) {
-                const int k = kb + 16 * q + 4 * g;
-                rl_load_k4(A, row, rok && kb + 16 * q < KA, KA, k, vecA, a[q]);
+            for (int s = 0; s < 4; ++s) a[s] = yv[s] > 0.0f ? a[s] : a[s] * slope_in;
+        }
+        const float *bk = rl_lds + 4 * g + r * KS;
+#pragma unroll 1
+        for (int k0 = 0; k0 < K16; k0 += 16) {
+            rl_load_k4(A, row, rok && k0 + 16 < K16, KA, k0 + 16 + 4 * g, vecA, an);
+            if (Y != nullptr) {
+                float yv[4];
+                rl_load_k4(Y, row, rok && k0 + 16 < K16, KA, k0 + 16 + 4 * g, vecA, yv);
+#pragma unroll
+                for (int s = 0; s < 4; ++s) an[s] = yv[s] > 0.0f ? an[s] : an[s] * slope_in;
             }
-            if (Y != nullptr) {                                       // gz = gy * lrelu'(z): sign(y) == sign(z)
 #pragma unroll
-                for (int q = 0; q < RL_KB / 16; ++q) {
-                    float yv[4];
-                    rl_load_k4(Y, row, rok && kb + 16 * q < KA, KA, kb + 16 * q + 4 * g, vecA, yv);
-#pragma unroll
-                    for (int s = 0; s < 4; ++s) a[q][s] = yv[s] > 0.0f ? a[q][s] : a[q][s] * slope_in;
+            for (int c = 0; c < RL_NP_MAX / 16; ++c) {
+                if (c < nt) {                                         // (wave-uniform)
+                    const float4 b = *reinterpret_cast<const float4 *>(bk + k0 + 16 * c * KS);
+                    acc[c] = RL_MFMA(a[0], b.x, acc[c]);
+                    acc[c] = RL_MFMA(a[1], b.y, acc[c]);
+                    acc[c] = RL_MFMA(a[2], b.z, acc[c]);
+                    acc[c] = RL_MFMA(a[3], b.w, acc[c]);
                 }
             }
 #pragma unroll
-            for (int q = 0; q < RL_KB / 16; ++q) {
-                if (kb + 16 * q < KA) {                               // (wave-uniform)
-                    const float *bk = rl_lds + kb + 16 * q + 4 * g;
-#pragma unroll
-                    for (int c = 0; c < RL_NP_MAX / 16; ++c) {
-                        if (c < nt) {
-                            const float4 b = *reinterpret_cast<const float4 *>(bk + (16 * c + r) * KS);
-                            acc[c] = RL_MFMA(a[q][0], b.x, acc[c]);
-                            acc[c] = RL_MFMA(a[q][1], b.y, acc[c]);
-                            acc[c] = RL_MFMA(a[q][2], b.z, acc[c]);
-                            acc[c] = RL_MFMA(a[q][3], b.w, acc[c]);
-                        }
-                    }
-                }
-            }
+            for (int s = 0; s < 4; ++s) a[s] = an[s];
         }
         // D[m = 4g + i][n = r] in register i
 #pragma unroll
@@ -391,7 +393,7 @@ WgradPlan wgrad_plan(long long Pseg, int nseg, int Cin, int Cout, int has_bias) 
 
 bool rl_args_ok(long long P, int nseg, int Cin, int Cout) {
     return P >= 0 && nseg >= 1 && Cin >= 1 && Cout >= 1 && Cin <= 1000 && Cout <= 1000 && P % nseg == 0 &&
-           (nseg == 1 || (P / nseg) % 64 == 0) && P < (1LL << 40);
+           (nseg == 1 || (P / nseg) % 128 == 0) && P < (1LL << 40);
 }
 
 bool rl_wgrad_fits(int Cin, int Cout, int has_bias) {
@@ -419,7 +421,7 @@ extern "C" int tpg_rowlinear_fwd(const void *x, int dtype_in, const float *W, co
     if ((dtype_in != TPG_DTYPE_F32 && dtype_in != TPG_DTYPE_BF16) || (dtype_out != TPG_DTYPE_F32 && dtype_out != TPG_DTYPE_BF16))
         return TPG_ERR_UNSUPPORTED;
     if ((reinterpret_cast<uintptr_t>(x) | reinterpret_cast<uintptr_t>(W)) & 15) return TPG_ERR_UNSUPPORTED;
-    const dim3 grid((unsigned)((P + 63) / 64)), blk(256);
+    const dim3 grid((unsigned)((P + RL_WG_ROWS - 1) / RL_WG_ROWS)), blk(RL_THREADS);
     hipStream_t st = tpg_stream(stream);
     const long long Pseg = P / nseg;
     const size_t smem = sizeof(float) * (size_t)rl_np(Cin, Cout) * rl_ks(Cin);
@@ -444,7 +446,7 @@ extern "C" int tpg_rowlinear_dgrad(const void *gy, const void *y, int dtype_g, c
         return TPG_ERR_UNSUPPORTED;
     if ((reinterpret_cast<uintptr_t>(gy) | reinterpret_cast<uintptr_t>(y) | reinterpret_cast<uintptr_t>(W)) & 15)
         return TPG_ERR_UNSUPPORTED;
-    const dim3 grid((unsigned)((P + 63) / 64)), blk(256);
+    const dim3 grid((unsigned)((P + RL_WG_ROWS - 1) / RL_WG_ROWS)), blk(RL_THREADS);
     hipStream_t st = tpg_stream(stream);
     const long long Pseg = P / nseg;
     const void *yy = slope != 1.0f ? y : nullptr;

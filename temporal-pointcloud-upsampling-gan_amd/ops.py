@@ -1471,12 +1471,13 @@ class _RowLinear(torch.autograd.Function):
         return dx, dW, db, None, None, None
 
 
-# Off by default (round 3 measurement, tools/tune_rowlinear.py, hipGraph replay, MI355X): the hand-written kernels are
-# correct on every shape of the step (tests/test_mlp_gpu.py) but 1.2-5x SLOWER than the library GEMMs they would
-# replace -- 12288 x 128 -> 128 bf16: 44 us against 10 us forward, 148 against 40 us forward + backward; 8192 x 515 -> 256
-# in 4 segments: 597 against 32 us -- so the saved bias / activation / cast / partial-sum launches (~5 us each) do not
-# pay: the cfg2 step went from 13.5 to 21.7 ms with them on.  What they lack is known (480 live registers from the fully
-# unrolled k loop = one wave per SIMD; the weight re-staged per 64 rows); until that is fixed the library route stays.
+# Off by default (round 3 measurement, tools/tune_rowlinear.py -> profiles/r03_tune_rowlinear.txt, hipGraph replay,
+# MI355X): the hand-written kernels are correct on every shape of the step (tests/test_mlp_gpu.py) and win the FORWARD at
+# the small channel counts (12288 x 3 -> 64: 6.0 against 7.6 us; 196608 x 6 -> 64 in six segments: 22 against 38 us) but lose
+# forward + backward everywhere (12288 x 128 -> 128 bf16: 95 against 39 us; 8192 x 515 -> 256 in four segments: 847 against
+# 132 us): the f32 matrix rate bounds the wide layers (the pre-gather layers must stay fp32), the weight is staged per 128
+# rows and once per 16-column pass when K is large, and the weight gradient walks its slabs on too few CUs.  The ~5 us
+# saved per fused bias / activation / cast / partial-sum launch do not pay for that: the library route stays.
 ROW_LINEAR = [False]
 
 
@@ -1488,7 +1489,7 @@ def row_linear_supported(x, W, nseg=1):
     P = x.numel() // x.shape[-1] if x.numel() else 0
     if P == 0 or not _lib.load().tpg_rowlinear_supported(int(x.shape[-1]), int(W.shape[-2]), 1):
         return False
-    return nseg == 1 or (P % nseg == 0 and (P // nseg) % 64 == 0)
+    return nseg == 1 or (P % nseg == 0 and (P // nseg) % 128 == 0)
 
 
 def row_linear(x, W, bias=None, slope=1.0, nseg=1, out_dtype=None):
