@@ -105,6 +105,15 @@ int tpg_chamfer_bwd_f32(const float *src, const float *tgt, int B, int N, int M,
 int tpg_fps_f32(const float *xyz, int B, int N, int m, float *temp, int32_t *idx,
                 void *stream);
 
+/* The same sampling with the "FPS of an FPS prefix" shortcut (round 3; csrc/fps.hip): every set-abstraction level after
+ * the first samples the centres of the level before, in pick order (discriminator.py:114 on :131-137's gather), and
+ * the furthest point sampling of such a prefix is 0, 1, ..., m-1 as long as the producing sampling's last maximum was
+ * positive.  prefix_out (B) int32 (may be NULL): set to that condition per cloud; prefix_in (B) int32 (may be NULL):
+ * the producing launch's flags -- clouds whose flag is set get 0..m-1 without a single round, the others the full
+ * algorithm.  Results are identical to tpg_fps_f32 in every case. */
+int tpg_fps_prefix_f32(const float *xyz, int B, int N, int m, float *temp, int32_t *idx,
+                       const int32_t *prefix_in, int32_t *prefix_out, void *stream);
+
 /* Dataset-side farthest point sampling: sampling.py:50-106 `farthest_point_sampling(pts, k,
  * initial_idx)` (used by train_utils.py:126, train_fluid/tempo_dataset.py:78,
  * train_action/msr_dataset.py:94,130 on the host, numba): start (B) int32 = first pick per cloud

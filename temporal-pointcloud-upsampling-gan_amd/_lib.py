@@ -26,6 +26,7 @@ SIGNATURES = {
     "tpg_chamfer_fwd_f32": [_P, _P, _I, _I, _I, _P, _P, _P, _P, _P],
     "tpg_chamfer_bwd_f32": [_P, _P, _I, _I, _I, _P, _P, _P, _P, _P, _P, _P, _P],
     "tpg_fps_f32": [_P, _I, _I, _I, _P, _P, _P],
+    "tpg_fps_prefix_f32": [_P, _I, _I, _I, _P, _P, _P, _P, _P],
     "tpg_fps_start_f32": [_P, _P, _I, _I, _I, _I, _P, _P, _P],
     "tpg_gather_fwd_f32": [_P, _P, _I, _I, _I, _I, _P, _P],
     "tpg_gather_bwd_f32": [_P, _P, _I, _I, _I, _I, _P, _P],

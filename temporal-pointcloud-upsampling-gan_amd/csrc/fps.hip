@@ -49,6 +49,24 @@ __device__ __forceinline__ tpg_u64 fps_key(float d2, int k) {
     return ((tpg_u64)(__float_as_uint(d2) + 1u) << 32) | (unsigned)(~k);
 }
 
+// FPS OF AN FPS PREFIX (round 3).  Let S = the first M picks of a furthest point sampling of a cloud, in pick order, and
+// sample m <= M points of S with the same rule (start at its point 0).  Round j of that second sampling maximises, over S,
+// the minimum distance to S[0..j): the very quantity the first sampling maximised over the WHOLE cloud when it chose
+// S[j], computed by the same fp32 operations -- so S[j] attains the maximum over S as well, every candidate tied with it
+// sits at a later position, and the picks are 0, 1, ..., m-1 as long as that maximum was POSITIVE (with a maximum of 0
+// -- fewer distinct eligible points than picks -- ties reach back to already chosen positions).  Every set-abstraction
+// level after the first samples exactly such a prefix (discriminator.py:114 on the centres of the level before,
+// :131-137), so the producing launch leaves a per-cloud flag "my last maximum was positive" (prefix_out) and the
+// consuming launch (prefix_in) writes 0..m-1 and returns when it is set -- same result, no rounds -- and runs the full
+// algorithm when it is not.  A launch that took the shortcut hands the flag on.
+__device__ __forceinline__ bool tpg_fps_prefix_shortcut(const int32_t *prefix_in, int32_t *prefix_out, const int32_t *start,
+                                                        int32_t *out, int m, int N, int tid, int nthreads) {
+    if (prefix_in == nullptr || start != nullptr || m > N || prefix_in[blockIdx.x] == 0) return false;   // (block-uniform)
+    for (int j = tid; j < m; j += nthreads) out[j] = j;
+    if (tid == 0 && prefix_out) prefix_out[blockIdx.x] = 1;
+    return true;
+}
+
 // Running distances are kept as float BITS compared as signed ints: every distance is >= +0,
 // whose bit patterns order like ints, and the single negative value -1.0f marks "not eligible"
 // (|x|^2 <= 1e-3, or padding) -- min(d, -1) stays -1 and -1 never beats the initial best = -1,
@@ -56,7 +74,9 @@ __device__ __forceinline__ tpg_u64 fps_key(float d2, int k) {
 template <int BLOCK, int PPT, bool USE_LDS>
 __global__ __launch_bounds__(BLOCK) void fps_kernel(const float *__restrict__ xyz, int N, int m,
                                                     int32_t *__restrict__ idx,
-                                                    const int32_t *__restrict__ start, int skip_origin) {
+                                                    const int32_t *__restrict__ start, int skip_origin,
+                                                    const int32_t *__restrict__ prefix_in,
+                                                    int32_t *__restrict__ prefix_out) {
     extern __shared__ __attribute__((aligned(16))) float fps_smem[];
     constexpr int NW = BLOCK / 64;
     // layout: [2][16] (value,index) slots (256 B), [2][16] xyz of each wave's winner (768 B: clouds too
@@ -71,6 +91,7 @@ __global__ __launch_bounds__(BLOCK) void fps_kernel(const float *__restrict__ xy
     const int wave = tid >> 6;
     const float *x = xyz + (size_t)blockIdx.x * N * 3;
     int32_t *out = idx + (size_t)blockIdx.x * m;
+    if (tpg_fps_prefix_shortcut(prefix_in, prefix_out, start, out, m, N, (int)threadIdx.x, BLOCK)) return;
 
     float px[PPT], py[PPT], pz[PPT];
     int tp[PPT];                          // running min distance, as float bits (see above)
@@ -181,16 +202,21 @@ __global__ __launch_bounds__(BLOCK) void fps_kernel(const float *__restrict__ xy
             ox = mx >= 0 ? wv.x : zx; oy = mx >= 0 ? wv.y : zy; oz = mx >= 0 ? wv.z : zz;
         }
         if (tid == 0) out[j] = old;
+        if (j == m - 1 && tid == 0 && prefix_out) prefix_out[blockIdx.x] = mx > 0 ? 1 : 0;   // last (= smallest) maximum
     }
+    if (m == 1 && tid == 0 && prefix_out) prefix_out[blockIdx.x] = 1;
 }
 
 // fallback for clouds too large for registers: running distances in HBM scratch.
 __global__ __launch_bounds__(1024) void fps_big_kernel(const float *__restrict__ xyz, int N, int m,
                                                        float *__restrict__ temp,
                                                        int32_t *__restrict__ idx,
-                                                       const int32_t *__restrict__ start, int skip_origin) {
+                                                       const int32_t *__restrict__ start, int skip_origin,
+                                                       const int32_t *__restrict__ prefix_in,
+                                                       int32_t *__restrict__ prefix_out) {
     __shared__ tpg_u64 slots[2][16];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    if (tpg_fps_prefix_shortcut(prefix_in, prefix_out, start, idx + (size_t)blockIdx.x * m, m, N, tid, 1024)) return;
     const float *x = xyz + (size_t)blockIdx.x * N * 3;
     float *tp = temp + (size_t)blockIdx.x * N;
     int32_t *out = idx + (size_t)blockIdx.x * m;
@@ -227,12 +253,15 @@ __global__ __launch_bounds__(1024) void fps_big_kernel(const float *__restrict__
         key = tpg_readlane_u64(v, 0);
         old = key ? (int)(~(unsigned)key) : 0;
         if (tid == 0) out[j] = old;
+        // (the key's upper word is the distance's bits + 1: > 1 <=> a positive distance)
+        if (j == m - 1 && tid == 0 && prefix_out) prefix_out[blockIdx.x] = (key >> 32) > 1ull ? 1 : 0;
     }
+    if (m == 1 && tid == 0 && prefix_out) prefix_out[blockIdx.x] = 1;
 }
 
 template <int BLOCK, int PPT>
 void fps_go(const float *xyz, int B, int N, int m, int32_t *idx, const int32_t *start, int skip_origin,
-            hipStream_t st) {
+            const int32_t *pin, int32_t *pout, hipStream_t st) {
 #ifdef TPG_FPS_NO_LDS_COPY
     int use_lds = 0;
 #else
@@ -257,16 +286,16 @@ void fps_go(const float *xyz, int B, int N, int m, int32_t *idx, const int32_t *
     }
     if (use_lds)
         hipLaunchKernelGGL((fps_kernel<BLOCK, PPT, true>), dim3(B), dim3(BLOCK), smem, st, xyz, N, m, idx, start,
-                           skip_origin);
+                           skip_origin, pin, pout);
     else
         hipLaunchKernelGGL((fps_kernel<BLOCK, PPT, false>), dim3(B), dim3(BLOCK), smem, st, xyz, N, m, idx, start,
-                           skip_origin);
+                           skip_origin, pin, pout);
 }
 
 }  // namespace
 
-extern "C" int tpg_fps_start_f32(const float *xyz, const int32_t *start, int skip_origin, int B, int N, int m,
-                                 float *temp, int32_t *idx, void *stream) {
+static int fps_dispatch(const float *xyz, const int32_t *start, int skip_origin, int B, int N, int m, float *temp,
+                        int32_t *idx, const int32_t *pin, int32_t *pout, void *stream) {
     if (B < 0 || N <= 0 || m <= 0) return TPG_ERR_ARG;
     if (B == 0) return TPG_OK;
     if (!xyz || !idx) return TPG_ERR_ARG;
@@ -275,7 +304,7 @@ extern "C" int tpg_fps_start_f32(const float *xyz, const int32_t *start, int ski
     // thread before more waves -- a round is VALU-issue bound on its one CU, and every extra wave
     // repeats the reduction and lengthens the barrier.  (4096 points: 0.57 us/round with 256 threads,
     // 0.59 with 512, 0.63 with 1024.)
-#define TPG_FPS_SHAPE(n, block) fps_go<block, (n) / (block)>(xyz, B, N, m, idx, start, skip_origin, st)
+#define TPG_FPS_SHAPE(n, block) fps_go<block, (n) / (block)>(xyz, B, N, m, idx, start, skip_origin, pin, pout, st)
 #ifndef TPG_FPS_1024_BLOCK
 #define TPG_FPS_1024_BLOCK 256
 #endif
@@ -297,13 +326,23 @@ extern "C" int tpg_fps_start_f32(const float *xyz, const int32_t *start, int ski
     else if (N <= 16384) TPG_FPS_SHAPE(16384, 1024);
     else {
         if (!temp) return TPG_ERR_ARG;
-        hipLaunchKernelGGL(fps_big_kernel, dim3(B), dim3(1024), 0, st, xyz, N, m, temp, idx, start, skip_origin);
+        hipLaunchKernelGGL(fps_big_kernel, dim3(B), dim3(1024), 0, st, xyz, N, m, temp, idx, start, skip_origin, pin, pout);
     }
     TPG_RETURN_IF_LAUNCH_FAILED();
     return TPG_OK;
 }
 
+extern "C" int tpg_fps_start_f32(const float *xyz, const int32_t *start, int skip_origin, int B, int N, int m,
+                                 float *temp, int32_t *idx, void *stream) {
+    return fps_dispatch(xyz, start, skip_origin, B, N, m, temp, idx, nullptr, nullptr, stream);
+}
+
 extern "C" int tpg_fps_f32(const float *xyz, int B, int N, int m, float *temp, int32_t *idx,
                            void *stream) {
-    return tpg_fps_start_f32(xyz, nullptr, 1, B, N, m, temp, idx, stream);     // pointnet2 semantics
+    return fps_dispatch(xyz, nullptr, 1, B, N, m, temp, idx, nullptr, nullptr, stream);     // pointnet2 semantics
+}
+
+extern "C" int tpg_fps_prefix_f32(const float *xyz, int B, int N, int m, float *temp, int32_t *idx,
+                                  const int32_t *prefix_in, int32_t *prefix_out, void *stream) {
+    return fps_dispatch(xyz, nullptr, 1, B, N, m, temp, idx, prefix_in, prefix_out, stream);
 }

@@ -152,6 +152,16 @@ class GraphedFluidStep:
         self.sides = [torch.cuda.Stream(dev) for _ in range(2)]
         self.branch = torch.cuda.Stream(dev)       # the discriminators' updates
         self.branch2 = torch.cuda.Stream(dev)
+        # round 3: two more parallel branches INSIDE the generator step -- the generator's mask head beside its
+        # upsampling head (srnet.SRNet.body), and the spatial discriminator's forward (hence backward) of the generator
+        # step beside the temporal one's.  TPGAN_GSTEP_BRANCHES=0: the serial form (A/B timing).
+        mode = os.environ.get("TPGAN_GSTEP_BRANCHES", "0")         # "heads", "dis", "1" = both, "0" = none
+        self.gstep_branches = mode in ("1", "dis")
+        self.aux = torch.cuda.Stream(dev)
+        self.aux2 = torch.cuda.Stream(dev)
+        if mode in ("1", "heads") and hasattr(sr_net, "filter_block"):
+            from .srnet import set_aux_stream
+            set_aux_stream(sr_net, self.aux)
         self.use_plans = True
         self._keep = {}
         self._graphs = None
@@ -233,9 +243,30 @@ class GraphedFluidStep:
             self.Ds.prepare_sn(1)
             self.Dt.prepare_sn(self.T, 1)
 
+    def _spatial_term(self, forward, join_plan, inputs, lab):
+        """The generator step's spatial-discriminator term (train_step_final.py:120-122), issued FIRST (the heads'
+        dropout draws keep the eager step's order) on its own stream when `gstep_branches`: it then runs -- forward
+        and backward -- beside the temporal discriminator's.  -> the loss tensor (`_join_spatial_term` before use)."""
+        if not self.gstep_branches:
+            join_plan()
+            return (0.5 * (forward().float() - lab[2]) ** 2).mean()
+        main = torch.cuda.current_stream(self.dev)
+        self.aux2.wait_stream(main)
+        with torch.cuda.stream(self.aux2):
+            join_plan()
+            for t in inputs:
+                t.record_stream(self.aux2)
+            loss = (0.5 * (forward().float() - lab[2]) ** 2).mean()
+        return loss
+
+    def _join_spatial_term(self, loss):
+        if self.gstep_branches:
+            torch.cuda.current_stream(self.dev).wait_stream(self.aux2)
+            loss.record_stream(torch.cuda.current_stream(self.dev))
+
     def _join_sides(self, stream=None):
         stream = stream or torch.cuda.current_stream(self.dev)
-        for sd in self.sides:
+        for sd in self.sides + [self.aux, self.aux2]:
             stream.wait_stream(sd)
 
     def _seg_generator(self, update_D, defer_backward=False):
@@ -288,12 +319,11 @@ class GraphedFluidStep:
             # this stream is about to wait ~0.5 ms for the index plans: the power iterations of the
             # two forwards below (they depend on the weights alone) fill the gap
             self._prepare_sn_in_gap()
-            join_fs()
-            fake = Ds(fake_s_in, plan=plan_fs)
-            spatial_loss = (0.5 * (fake.float() - lab[2]) ** 2).mean()
+            spatial_loss = self._spatial_term(lambda: Ds(fake_s_in, plan=plan_fs), join_fs, [fake_s_in] + _plan_tensors(plan_fs), lab)
             join_ft()
             fake = Dt.forward_passes([fake_t_in], opt.R, plan=plan_ft)[0]
             tempo_loss = (0.5 * (fake.float() - lab[3]) ** 2).mean()
+            self._join_spatial_term(spatial_loss)
         sr_loss = tempo_loss + spatial_loss + opt.w * position_loss
         k.update(tempo_loss=tempo_loss.detach(), spatial_loss=spatial_loss.detach(), cd=cd.detach(), ml=ml.detach())
         self.viol.copy_(viol.float().reshape(1))
@@ -481,7 +511,7 @@ class GraphedFluidStep:
                     except BaseException:
                         # leave the capture joinable: an unjoined side stream turns the original
                         # error into "capturing stream has unjoined work" and poisons the stream
-                        self._join_sides()
+                        self._join_sides()                   # (index-plan streams and the generator step's branches)
                         torch.cuda.current_stream(self.dev).wait_stream(self.branch)
                         torch.cuda.current_stream(self.dev).wait_stream(self.branch2)
                         raise
@@ -648,12 +678,11 @@ class GraphedActionStep(GraphedFluidStep):
                 lambda: [p.detach() for p in pred_lst])
             position_loss, cd, _ = tpugan_sr_loss(0, high[1], pred_c, 0., 0., 0., 0)
             self._prepare_sn_in_gap()
-            join_fs()
-            fake = Ds(fake_s_in, plan=plan_fs)
-            spatial_loss = (0.5 * (fake.float() - lab[2]) ** 2).mean()
+            spatial_loss = self._spatial_term(lambda: Ds(fake_s_in, plan=plan_fs), join_fs, [fake_s_in] + _plan_tensors(plan_fs), lab)
             join_ft()
             fake = Dt.forward_passes([pred_lst], opt.R, plan=plan_ft)[0]
             tempo_loss = (0.5 * (fake.float() - lab[3]) ** 2).mean()
+            self._join_spatial_term(spatial_loss)
         sr_loss = tempo_loss + spatial_loss + opt.w * position_loss
         k.update(tempo_loss=tempo_loss.detach(), spatial_loss=spatial_loss.detach(), cd=cd.detach(),
                  ml=torch.zeros((), device=self.dev))

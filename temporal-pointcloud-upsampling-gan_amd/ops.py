@@ -246,6 +246,17 @@ class HipBackend:
                    _ptr(src), _ptr(tgt), B, N, M, _ptr(i1), _ptr(i2), _ptr(g1), _ptr(g2), _ptr(gs), _ptr(gt), _ptr(ws))
         return gs, gt
 
+    def fps_prefix(self, xyz, m, prefix_in=None):
+        """pointnet2's FPS + the per-cloud flag the next level's sampling of these centres may shortcut on
+        (tpg_fps_prefix_f32); prefix_in: the flags of the launch that PRODUCED xyz's order, or None."""
+        B, N, _ = xyz.shape
+        idx = torch.empty((B, m), dtype=torch.int32, device=xyz.device)
+        flag = torch.empty((B,), dtype=torch.int32, device=xyz.device)
+        temp = torch.empty((B, N), dtype=torch.float32, device=xyz.device) if N > 16384 else None
+        self._call("tpg_fps_prefix_f32", "fps" if prefix_in is None else "fps_prefix", 12 * B * N + 4 * B * m, xyz,
+                   _ptr(xyz), B, N, m, _ptr(temp), _ptr(idx), _ptr(prefix_in), _ptr(flag))
+        return idx, flag
+
     def fps(self, xyz, m, start=None, skip_origin=True):
         B, N, _ = xyz.shape
         idx = torch.empty((B, m), dtype=torch.int32, device=xyz.device)
@@ -770,6 +781,20 @@ def furthest_point_sample(xyz, npoint):
     _need(int(npoint) > 0 and xyz.shape[1] > 0, "npoint and N must be positive")
     with torch.no_grad():
         return backend_for(xyz).fps(xyz.detach(), int(npoint))
+
+
+def furthest_point_sample_prefix(xyz, npoint, prefix_flag=None):
+    """`furthest_point_sample` for a chain of set-abstraction levels: -> (idx (B,npoint) int32, flag (B,) int32).
+    `prefix_flag` = the flag returned by the call that sampled the centres `xyz` consists of (xyz must be those centres
+    in pick order): clouds whose flag is set are answered with 0..npoint-1 at once -- the exact result, see
+    csrc/fps.hip -- the others by the full algorithm.  Backends without the entry fall back to the plain op."""
+    _check_float(xyz, "xyz", 3)
+    _need(xyz.shape[2] == 3 and int(npoint) > 0 and xyz.shape[1] > 0, "xyz must be (B,N,3), npoint and N positive")
+    be = backend_for(xyz)
+    with torch.no_grad():
+        if hasattr(be, "fps_prefix"):
+            return be.fps_prefix(xyz.detach(), int(npoint), prefix_flag)
+        return be.fps(xyz.detach(), int(npoint)), None
 
 
 def farthest_point_sampling(pts, k, initial_idx=None):

@@ -379,20 +379,29 @@ class _PointnetSAModuleBase(nn.Module):
         # host sync per call without changing any result)
         self.check_dummies = True
 
-    def sample_centres(self, xyz):
+    def sample_centres(self, xyz, prefix=None):
+        """FPS centres of this level.  prefix: a one-element list holding the flag tensor of the sampling that produced
+        xyz's ORDER (xyz = the previous level's centres, in pick order) or None; it is replaced by this level's flag
+        for the level after (ops.furthest_point_sample_prefix: the sampling of an FPS prefix is 0..m-1, exactly)."""
+        if prefix is not None and xyz.is_cuda and not (self.mask_dummy and self.check_dummies):
+            centres, prefix[0] = ops.furthest_point_sample_prefix(xyz, self.npoint, prefix[0])
+            return centres
+        if prefix is not None:
+            prefix[0] = None                     # (dummy replacement re-orders the centres: no shortcut downstream)
         centres = ops.furthest_point_sample(xyz, self.npoint)
         if self.mask_dummy and self.check_dummies:
             centres = replace_dummy_centres(xyz, centres)
         return centres
 
-    def index_level(self, xyz, inverse=True):
+    def index_level(self, xyz, inverse=True, prefix=None):
         """All index-only work of this level for detached clouds xyz (B,N,3):
         -> (centres (B,S) int32, new_xyz (B,S,3) detached, idx (B,S,ns) int32).
         It depends on coordinates only, so a caller may run it ahead of time / on another stream
         (see `index_plan` of the discriminators) and hand the result to `forward_rows`.
-        inverse=False leaves the inverted index to whoever regroups the lists (`merge_plans`)."""
+        inverse=False leaves the inverted index to whoever regroups the lists (`merge_plans`).
+        prefix: see `sample_centres` (pass the same list to every level of a chain, [None] at the first)."""
         xyz = xyz.detach().float().contiguous()
-        centres = self.sample_centres(xyz)
+        centres = self.sample_centres(xyz, prefix)
         new_xyz = ops.gather_operation(xyz.transpose(1, 2).contiguous(), centres).transpose(1, 2).contiguous()
         g = self.groupers[0]
         idx = _sources(ops.ball_query(g.radius, g.nsample, xyz, new_xyz), xyz.shape[1])
@@ -800,8 +809,9 @@ class _TempoDis(nn.Module):
         coordinates only; see `run_index_plan` for running it on a side stream."""
         T, B = len(pos_lst), pos_lst[0].shape[0]
         xyz = torch.cat([p.detach().float() for p in pos_lst], 0)
-        c0, x1, i0 = self.coarse_graining_module[0].index_level(xyz)
-        c1, x2, i1 = self.coarse_graining_module[1].index_level(x1)
+        chain = [None]                              # level 1 samples level 0's centres: FPS-prefix shortcut
+        c0, x1, i0 = self.coarse_graining_module[0].index_level(xyz, prefix=chain)
+        c1, x2, i1 = self.coarse_graining_module[1].index_level(x1, prefix=chain)
         pairs = self.flow_module.pair_indices([x2[t * B:(t + 1) * B] for t in range(T)],
                                               self.flow_radius_scale * cutoff)
         return {"sa": [(c0, i0), (c1, i1)], "flow": pairs}
@@ -814,8 +824,9 @@ class _TempoDis(nn.Module):
         inverted indices: hand them to `merge_plans` (or `attach_plan_inverses`)."""
         NP, T, B = len(pos_lsts), len(pos_lsts[0]), pos_lsts[0][0].shape[0]
         xyz = torch.cat([p.detach().float() for pos_lst in pos_lsts for p in pos_lst], 0)   # pass-major
-        c0, x1, i0 = self.coarse_graining_module[0].index_level(xyz, inverse=False)
-        c1, x2, i1 = self.coarse_graining_module[1].index_level(x1, inverse=False)
+        chain = [None]
+        c0, x1, i0 = self.coarse_graining_module[0].index_level(xyz, inverse=False, prefix=chain)
+        c1, x2, i1 = self.coarse_graining_module[1].index_level(x1, inverse=False, prefix=chain)
         frames = x2.view(NP, T, B, *x2.shape[1:])
         pairs = self.flow_module.pair_indices([frames[:, t].reshape(NP * B, *x2.shape[1:]) for t in range(T)],
                                               self.flow_radius_scale * cutoff, inverse=False)
@@ -967,17 +978,17 @@ class _SpatialDis(nn.Module):
         """[index_plan(p) for p in pos_list] with every search launched once for all passes (see
         _TempoDis.index_plans); per-pass plans without inverted indices."""
         NP, B = len(pos_list), pos_list[0].shape[0]
-        xyz, levels = torch.cat([p.detach().float() for p in pos_list], 0), []
+        xyz, levels, chain = torch.cat([p.detach().float() for p in pos_list], 0), [], [None]
         for sa in self.coarse_graining_module:
-            c, xyz, i = sa.index_level(xyz, inverse=False)
+            c, xyz, i = sa.index_level(xyz, inverse=False, prefix=chain)
             levels.append((c, i))
         return [{"sa": [(c[p * B:(p + 1) * B], _cut(i, p * B, (p + 1) * B)) for c, i in levels]} for p in range(NP)]
 
     def index_plan(self, pos):
         """FPS centres + ball-query lists of every level for the clouds `pos` (coordinates only)."""
-        xyz, levels = pos.detach().float(), []
+        xyz, levels, chain = pos.detach().float(), [], [None]
         for sa in self.coarse_graining_module:
-            c, xyz, i = sa.index_level(xyz)
+            c, xyz, i = sa.index_level(xyz, prefix=chain)
             levels.append((c, i))
         return {"sa": levels}
 

@@ -13,6 +13,21 @@ from .graph_conv import (EdgeConv, IDGCNLayer, build_shared_mlp, conv_bn_layer, 
                          rows_seq)
 
 
+# generator -> side stream for its mask head (set by gan_step_graph; a registry, not an attribute: modules are deep-copied
+# by tests and tools, streams are not)
+import weakref
+
+_AUX_STREAMS = weakref.WeakKeyDictionary()
+
+
+def set_aux_stream(net, stream):
+    """Run `net`'s mask head on `stream`, beside its upsampling head (None: back to one stream)."""
+    if stream is None:
+        _AUX_STREAMS.pop(net, None)
+    else:
+        _AUX_STREAMS[net] = stream
+
+
 class GCNFeatureExtractor(nn.Module):
     def __init__(self, layer_num, in_node_feat_dim, out_node_feat_dim, node_emb_dim=128):
         super().__init__()
@@ -140,6 +155,21 @@ class SRNet(nn.Module):
     def body(self, feature, pos):
         if rows_first():
             enc = self.feature_extractor.forward_rows(feature, pos if self.in_feats > 3 else None)
+            aux = _AUX_STREAMS.get(self)
+            if aux is not None and enc.is_cuda:
+                # The two heads (upsampling_network.py:44-74 and :77-104) read the same encoding and nothing of each
+                # other: on two streams they are parallel branches of a captured step -- forward AND backward (autograd
+                # runs a node's backward on its forward stream) -- on a chain of ~5 us kernels that cannot fill the
+                # chip alone (round 3; set by gan_step_graph).
+                main = torch.cuda.current_stream(enc.device)
+                aux.wait_stream(main)
+                with torch.cuda.stream(aux):
+                    mask = self.filter_block.forward_rows(enc).float()
+                enc.record_stream(aux)
+                edge = self.upsampling_block.forward_rows(enc).float()
+                main.wait_stream(aux)
+                mask.record_stream(main)
+                return edge, mask
             return self.upsampling_block.forward_rows(enc).float(), self.filter_block.forward_rows(enc).float()
         enc = self.feature_extractor(feature, pos) if self.in_feats > 3 else self.feature_extractor(feature)
         return self.upsampling_block(enc).float(), self.filter_block(enc).float()

@@ -211,6 +211,60 @@ def test_fps_duplicate_points_tie_to_smallest_index(hip):
     assert np.array_equal(hip.fps(dev(x), 100).cpu().numpy(), R.fps(x, 100))
 
 
+def _gather_rows(x, idx):
+    return np.take_along_axis(x, idx[..., None].astype(np.int64), axis=1)
+
+
+@pytest.mark.parametrize("B,N,chain", [(3, 4096, (1024, 512, 128)), (4, 4096, (1024, 256)), (2, 16384, (1024, 512)),
+                                       (1, 20000, (300, 100)), (2, 2048, (512, 256, 128)), (2, 300, (64, 64, 7))])
+def test_fps_of_an_fps_prefix_is_the_full_algorithm(hip, B, N, chain):
+    """tpg_fps_prefix_f32 (round 3): a set-abstraction level samples the centres of the level before, in pick order,
+    and the sampling of such a prefix is 0..m-1 whenever the producing sampling's last maximum was positive.  Every
+    level of a chain, with the flags handed on, against the FULL kernel and the oracle on the same gathered centres
+    -- bit for bit -- and the flags must be set on benign clouds (so the shortcut really ran)."""
+    rng = np.random.default_rng(N + len(chain))
+    x = fluid(rng, B, N)
+    x[:, N // 3] = x[:, N // 3 + 1]                      # a duplicate pair somewhere in the cloud
+    cur, flag = x, None
+    for level, m in enumerate(chain):
+        idx, flag = hip.fps_prefix(dev(cur), m, flag)
+        full = hip.fps(dev(cur), m)
+        assert torch.equal(idx, full), (level, m)
+        assert np.array_equal(idx.cpu().numpy(), R.fps(cur, m)), (level, m)
+        assert flag.cpu().tolist() == [1] * B, (level, flag.cpu().tolist())
+        if level:
+            assert np.array_equal(idx.cpu().numpy(), np.broadcast_to(np.arange(m, dtype=np.int32), (B, m)))
+        cur = _gather_rows(cur, idx.cpu().numpy())
+
+
+def test_fps_prefix_declines_where_the_maximum_reached_zero(hip):
+    """Clouds with fewer distinct eligible points than picks: the producing sampling's last maximum is 0, its flag stays
+    clear and the consuming launch runs the full algorithm (whose ties reach back to chosen positions: NOT 0..m-1) --
+    per cloud, next to benign clouds of the same batch that do take the shortcut."""
+    rng = np.random.default_rng(12)
+    B, N, m0, m1 = 4, 1024, 256, 128
+    x = fluid(rng, B, N)
+    few = fluid(rng, 1, 40)[0]
+    x[1] = few[rng.integers(0, 40, N)]                    # 40 distinct points, 1024 copies
+    x[3, :, :] = 0.01                                     # every point inside the origin ball: none eligible
+    idx0, flag0 = hip.fps_prefix(dev(x), m0, None)
+    assert np.array_equal(idx0.cpu().numpy(), R.fps(x, m0))
+    assert flag0.cpu().tolist() == [1, 0, 1, 0]
+    x1 = _gather_rows(x, idx0.cpu().numpy())
+    idx1, flag1 = hip.fps_prefix(dev(x1), m1, flag0)
+    want = R.fps(x1, m1)
+    assert np.array_equal(idx1.cpu().numpy(), want)
+    assert np.array_equal(want[0], np.arange(m1)) and not np.array_equal(want[1], np.arange(m1))
+    assert flag1.cpu().tolist() == [1, 0, 1, 0]
+    # action-clip duplicates (1/8 of the points repeated) with enough distinct points: the shortcut holds
+    y = (0.4 * rng.standard_normal((2, 2048, 3))).astype(np.float32)
+    y[:, -256:] = y[:, :256]
+    i0, f0 = hip.fps_prefix(dev(y), 512, None)
+    y1 = _gather_rows(y, i0.cpu().numpy())
+    i1, f1 = hip.fps_prefix(dev(y1), 256, f0)
+    assert f0.cpu().tolist() == [1, 1] and np.array_equal(i1.cpu().numpy(), R.fps(y1, 256))
+
+
 # ------------------------------------------------------------------ ball query
 @pytest.mark.parametrize("B,N,S,r,ns", [
     (2, 4096, 1024, 0.10, 32), (2, 4096, 1024, 0.15, 32), (2, 1024, 512, 0.30, 32),
