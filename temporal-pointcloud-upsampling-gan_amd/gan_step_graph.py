@@ -42,7 +42,7 @@ import os
 import numpy as np
 import torch
 
-from .graph_conv import shadows
+from .graph_conv import shadows, wgrad_side_stream
 from .gan_step import _frozen, _autocast, _set_dummy_check, _NoSync, tempo_gan_step
 from .losses import tpugan_sr_loss
 from .set_abstraction import _plan_tensors, attach_plan_inverses, run_index_plan, sn_discard_prepared
@@ -163,6 +163,7 @@ class GraphedFluidStep:
             from .srnet import set_aux_stream
             set_aux_stream(sr_net, self.aux)
         self.use_plans = True
+        self.wgrad_side = os.environ.get("TPGAN_WGRAD_SIDE", "0") != "0"    # measured: 13.1 -> 14.5 ms with it (a cross-stream edge per weight costs ~40 us): off
         self._keep = {}
         self._graphs = None
         self._capture(lowres_pos_lst, highres_pos_lst, warmup)
@@ -400,7 +401,10 @@ class GraphedFluidStep:
             k["tempo_dis_loss"] = torch.zeros((), device=self.dev)
             k["spatial_dis_loss"] = torch.zeros((), device=self.dev)
         self.og.zero_grad(set_to_none=True)
-        sr_loss.backward()
+        # the generator's weight gradients leave its backward chain: computed on an index-plan stream (idle by now) as
+        # parallel leaves of the graph (graph_conv.wgrad_side_stream); the join below orders them before the optimizers
+        with wgrad_side_stream(main, self.sides[0] if self.wgrad_side else None):
+            sr_loss.backward()
         self._join_sides(main)                     # every branch rejoins (required inside a capture)
         if update_D:
             main.wait_stream(self.branch)

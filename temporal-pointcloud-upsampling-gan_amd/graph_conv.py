@@ -159,6 +159,43 @@ class shadows:
         return False
 
 
+# Weight gradients beside the chain.  Nothing downstream of a backward pass waits for dW before the optimizer,
+# but on ONE stream its launches (split-K product + sum of the partials, bias sum) sit between two data-gradient
+# launches of a latency-bound chain.  A step that owns a spare stream registers it here for the stream its
+# backward runs on (gan_step_graph: an index-plan stream, idle by then); the weight-gradient launches go there --
+# parallel leaves of the captured graph -- and the step joins that stream before its optimizers run.
+_WGRAD_SIDE = {}
+
+
+@contextlib.contextmanager
+def wgrad_side_stream(main, side):
+    """Inside: `_TallLinear*` backward passes running on stream `main` compute dW / db on `side`.  The caller makes
+    `main` (or whatever reads the gradients) wait for `side` afterwards."""
+    if side is None:
+        yield
+        return
+    _WGRAD_SIDE[main.cuda_stream] = side
+    try:
+        yield
+    finally:
+        _WGRAD_SIDE.pop(main.cuda_stream, None)
+
+
+def _wgrad_ctx(*reads):
+    """Context for the weight-gradient launches of a backward pass: the registered side stream (ordered behind
+    everything the current stream has issued, `reads` kept alive for it) or nothing."""
+    if not _WGRAD_SIDE or not reads[0].is_cuda:
+        return contextlib.nullcontext()
+    cur = torch.cuda.current_stream(reads[0].device)
+    side = _WGRAD_SIDE.get(cur.cuda_stream)
+    if side is None:
+        return contextlib.nullcontext()
+    side.wait_stream(cur)
+    for t in reads:
+        t.record_stream(side)
+    return torch.cuda.stream(side)
+
+
 class _TallLinear(torch.autograd.Function):
     """y = x @ W^T for TALL x (P rows >> C): same forward GEMM as F.linear, but the weight
     gradient dW = gy^T x -- a (Cout x Cin) output with K = P up to 2.6e5 -- is computed as a
@@ -187,21 +224,22 @@ class _TallLinear(torch.autograd.Function):
         P, cin, cout, e = xd.shape[0], xd.shape[1], wd.shape[0], xd.element_size()
         if ctx.needs_input_grad[0]:
             dx = ops.timed("gemm_dgrad", e * P * (cin + cout), 2 * P * cin * cout, gy, lambda: gy @ wd).to(ctx.x_dtype)
-        if ctx.needs_input_grad[1]:
-            S = _split_k(P, wd.shape[0], wd.shape[1])
-            if S > 1:
-                rows = P // S
-                head = S * rows
-                dw = ops.timed("gemm_wgrad", e * P * (cin + cout), 2 * P * cin * cout, gy,
-                               lambda: _mm_f32(torch.bmm, gy[:head].view(S, rows, -1).transpose(1, 2),
-                                               xd[:head].view(S, rows, -1))).sum(0)
-                if head < P:
-                    dw = dw + _mm_f32(torch.mm, gy[head:].t(), xd[head:])
-            else:
-                dw = _mm_f32(torch.mm, gy.t(), xd)
-            dw = dw.to(ctx.w_dtype)
-        if ctx.b_dtype is not None and ctx.needs_input_grad[2]:
-            db = gy.sum(0, dtype=torch.float32).to(ctx.b_dtype)
+        with _wgrad_ctx(gy, xd):
+            if ctx.needs_input_grad[1]:
+                S = _split_k(P, wd.shape[0], wd.shape[1])
+                if S > 1:
+                    rows = P // S
+                    head = S * rows
+                    dw = ops.timed("gemm_wgrad", e * P * (cin + cout), 2 * P * cin * cout, gy,
+                                   lambda: _mm_f32(torch.bmm, gy[:head].view(S, rows, -1).transpose(1, 2),
+                                                   xd[:head].view(S, rows, -1))).sum(0)
+                    if head < P:
+                        dw = dw + _mm_f32(torch.mm, gy[head:].t(), xd[head:])
+                else:
+                    dw = _mm_f32(torch.mm, gy.t(), xd)
+                dw = dw.to(ctx.w_dtype)
+            if ctx.b_dtype is not None and ctx.needs_input_grad[2]:
+                db = gy.sum(0, dtype=torch.float32).to(ctx.b_dtype)
         return dx, dw, db, None
 
 
@@ -252,16 +290,17 @@ class _TallLinearSeg(torch.autograd.Function):
             dx = ops.timed("gemm_dgrad", e * nseg * P * (cin + cout), 2 * nseg * P * cin * cout, gy,
                            lambda: torch.bmm(gy, wd)).view(nseg * P, cin).to(ctx.x_dtype)
         if ctx.needs_input_grad[1]:
-            S = _split_k(P, cout, cin)
-            rows = P // S
-            head = S * rows
-            part = ops.timed("gemm_wgrad", e * nseg * P * (cin + cout), 2 * nseg * P * cin * cout, gy,
-                             lambda: _mm_f32(torch.bmm, gy[:, :head].reshape(nseg * S, rows, cout).transpose(1, 2),
-                                             xd[:, :head].reshape(nseg * S, rows, cin)))
-            dw = part.view(nseg, S, cout, cin).sum(1) if S > 1 else part.view(nseg, cout, cin)
-            if head < P:
-                dw = dw + _mm_f32(torch.bmm, gy[:, head:].transpose(1, 2), xd[:, head:])
-            dw = dw.to(ctx.w_dtype)
+            with _wgrad_ctx(gy, xd):
+                S = _split_k(P, cout, cin)
+                rows = P // S
+                head = S * rows
+                part = ops.timed("gemm_wgrad", e * nseg * P * (cin + cout), 2 * nseg * P * cin * cout, gy,
+                                 lambda: _mm_f32(torch.bmm, gy[:, :head].reshape(nseg * S, rows, cout).transpose(1, 2),
+                                                 xd[:, :head].reshape(nseg * S, rows, cin)))
+                dw = part.view(nseg, S, cout, cin).sum(1) if S > 1 else part.view(nseg, cout, cin)
+                if head < P:
+                    dw = dw + _mm_f32(torch.bmm, gy[:, head:].transpose(1, 2), xd[:, head:])
+                dw = dw.to(ctx.w_dtype)
         return dx, dw, None
 
 

@@ -57,6 +57,7 @@ def autograd_node(evt):
     return None
 
 
+KERNEL_FILTER = [f for f in os.environ.get("KS_KERNEL", "").split(",") if f]     # only kernels whose name has one of these
 count = collections.Counter()
 time_us = collections.Counter()
 for evt in prof.events():
@@ -69,6 +70,8 @@ for evt in prof.events():
     for k in kernels:
         dur = k.duration
         if dur > max_us:
+            continue
+        if KERNEL_FILTER and not any(f in k.name for f in KERNEL_FILTER):
             continue
         where = autograd_node(evt) or own_frame(evt) or "?"
         key = (evt.name, where)
