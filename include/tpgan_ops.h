@@ -184,6 +184,21 @@ int tpg_rowcombine_bwd(const void *gout, const int32_t *idx, const int32_t *offs
                        const void *E, int mode, int dtype_in, int dtype_out, int B, int N, int S, int K,
                        int C, float slope, void *gU, void *gQE, void *stream);
 
+/* EdgeConv front end on ONE product (gcn_lib/pointnet/gcn.py:176-180,207-210: node_affine(group(f)) +
+ * edge_affine(group(f) - f_i), both 1x1 conv + LeakyReLU on the same grouped input).  With the two convolutions applied
+ * BEFORE the gather, their weights stack into one GEMM: Y (B,N,2C) = f [We; Wn]^T -- columns [0,C) = E = We f, columns
+ * [C,2C) = the node term before its activation -- and
+ *   out[b,n,k,:] = lrelu(Y[b,idx[b,n,k],C:2C], slope_a) + lrelu(Y[b,idx[b,n,k],0:C] - Y[b,n,0:C], slope_e)
+ * i.e. tpg_rowcombine_fwd(mode EDGE) reading both operands from one buffer with the node row's activation folded in.
+ * Y of dtype_in, idx (B,N,K) int32, out (B,N,K,C) of dtype_out; C as in tpg_rowcombine_fwd and C*sizeof(dtype_in) % 16 == 0.
+ * Backward: gY (B,N,2C) of dtype_in = [gE | gA * lrelu'(Y[:,C:2C])], atomics-free over the inverted index of idx
+ * (tpg_invert_index), bitwise reproducible. */
+int tpg_rowcombine_edge_fwd(const void *Y, const int32_t *idx, int dtype_in, int dtype_out, int B, int N, int K, int C,
+                            float slope_a, float slope_e, void *out, void *stream);
+int tpg_rowcombine_edge_bwd(const void *gout, const int32_t *idx, const int32_t *offs, const int32_t *list,
+                            const void *Y, int dtype_in, int dtype_out, int B, int N, int K, int C, float slope_a,
+                            float slope_e, void *gY, void *stream);
+
 /* ---- fused BatchNorm + LeakyReLU (+ max over K neighbours) on channels-last rows ----------
  * The [conv -> BatchNorm2d -> (Leaky)ReLU]* -> max-over-nsample tail of every shared MLP
  * (discriminator.py:63-78,145-150,279-282) on rows x (P,C), P = B*S*ns:

@@ -214,6 +214,24 @@ def rowcombine_bwd(gout, idx, E, mode, N, slope=0.2):
     return gU, gQE
 
 
+def rowcombine_edge_fwd(Y, idx, slope_a=0.2, slope_e=0.2):
+    """The EdgeConv front end on one product (include/tpgan_ops.h, tpg_rowcombine_edge_fwd; reference
+    gcn_lib/pointnet/gcn.py:176-180,207-210): Y (B,N,2C) = f [We; Wn]^T; restated over rowcombine_fwd(mode EDGE)."""
+    Y = _c(Y, np.float32)
+    Cc = Y.shape[2] // 2
+    A = Y[:, :, Cc:]
+    A = np.where(A > 0, A, A * np.float32(slope_a)).astype(np.float32)
+    return rowcombine_fwd(A, Y[:, :, :Cc], idx, 2, slope_e)
+
+
+def rowcombine_edge_bwd(gout, idx, Y, slope_a=0.2, slope_e=0.2):
+    Y = _c(Y, np.float32)
+    Cc = Y.shape[2] // 2
+    gU, gE = rowcombine_bwd(gout, idx, Y[:, :, :Cc], 2, Y.shape[1], slope_e)
+    gA = np.where(Y[:, :, Cc:] > 0, gU, gU * np.float32(slope_a)).astype(np.float32)
+    return np.concatenate([gE, gA], axis=2)
+
+
 # ---- fused BatchNorm + LeakyReLU (+ max over K) on rows: numpy restatement (float64 inside) of the
 # build's own fused form of [BatchNorm2d -> (Leaky)ReLU -> max over nsample]
 # (reference discriminator.py:63-78,145-150,279-282); equality with the reference is pinned at

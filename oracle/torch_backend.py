@@ -86,6 +86,12 @@ class OracleBackend:
         return _t(gU).to(in_dtype), (None if gQE is None else _t(gQE).to(in_dtype))
 
 
+    def rowcombine_edge_fwd(self, Y, idx, slope_a, slope_e, out_dtype):
+        return _t(R.rowcombine_edge_fwd(_np(Y.float()), _np(idx), slope_a, slope_e)).to(out_dtype)
+
+    def rowcombine_edge_bwd(self, gout, idx, Y, slope_a, slope_e, inverse=None):
+        return _t(R.rowcombine_edge_bwd(_np(gout.float()), _np(idx), _np(Y.float()), slope_a, slope_e)).to(Y.dtype)
+
     def cubic_interp(self, query, pos, field, cutoff):
         plain, pad, hits = R.cubic_interp(_np(query), _np(pos), _np(field), cutoff)
         return _t(plain), _t(pad), _t(hits)

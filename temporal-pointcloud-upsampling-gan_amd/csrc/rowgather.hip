@@ -125,7 +125,9 @@ template <typename TA, typename TB> struct Elems {
 template <typename TI, typename TO, int MODE>
 __global__ __launch_bounds__(256) void rowcombine_fwd_kernel(
     const TI *__restrict__ U, const TI *__restrict__ QE, const int32_t *__restrict__ idx, int N, int S,
-    int K, int C, float slope, TO *__restrict__ out, unsigned total, int xcd_order) {
+    int K, int C, float slope, TO *__restrict__ out, unsigned total, int xcd_order, int ld, float slope_u) {
+    // ld = row stride of U / QE in elements (C, or 2C when both are column halves of ONE product: the EdgeConv
+    // front end, tpg_rowcombine_edge_fwd); slope_u: EDGE only, LeakyReLU applied to the gathered U row (1 = none)
     constexpr int NE = Elems<TI, TO>::NE;
     constexpr int UF = TPG_RC_FWD_U;
     using In = RowIO<TI, NE>;
@@ -144,20 +146,21 @@ __global__ __launch_bounds__(256) void rowcombine_fwd_kernel(
         const unsigned b = bs / (unsigned)S;
         const int n = tpg_clamp_idx(idx[row], N);
         float u[NE];
-        In::load(U + ((size_t)b * N + n) * C + col, u);
+        In::load(U + ((size_t)b * N + n) * ld + col, u);
         if (MODE == MODE_SUB) {
             float q[NE];
-            In::load(QE + (size_t)bs * C + col, q);
+            In::load(QE + (size_t)bs * ld + col, q);
 #pragma unroll
             for (int i = 0; i < NE; ++i) u[i] = u[i] - q[i];
         } else if (MODE == MODE_EDGE) {
             float en[NE], es[NE];
-            In::load(QE + ((size_t)b * N + n) * C + col, en);
-            In::load(QE + (size_t)bs * C + col, es);   // S == N: centre row of E
+            In::load(QE + ((size_t)b * N + n) * ld + col, en);
+            In::load(QE + (size_t)bs * ld + col, es);   // S == N: centre row of E
 #pragma unroll
             for (int i = 0; i < NE; ++i) {
                 const float d = en[i] - es[i];
-                u[i] = u[i] + (d > 0.0f ? d : d * slope);
+                const float a = u[i] > 0.0f ? u[i] : u[i] * slope_u;
+                u[i] = a + (d > 0.0f ? d : d * slope);
             }
         }
         if (TPG_RC_NT_STORE) Out::store_stream(out + (size_t)row * C + col, u);
@@ -179,9 +182,9 @@ __global__ __launch_bounds__(256) void rowcombine_fwd_kernel(
 #pragma unroll
         for (int j = 0; j < UF; ++j) {
             n[j] = tpg_clamp_idx(n[j], N);
-            In::load(U + ((size_t)b[j] * N + n[j]) * C + col[j], u[j]);
-            if (MODE != MODE_GATHER) In::load(QE + (size_t)bs[j] * C + col[j], q[j]);      // centre row
-            if (MODE == MODE_EDGE) In::load(QE + ((size_t)b[j] * N + n[j]) * C + col[j], en[j]);
+            In::load(U + ((size_t)b[j] * N + n[j]) * ld + col[j], u[j]);
+            if (MODE != MODE_GATHER) In::load(QE + (size_t)bs[j] * ld + col[j], q[j]);      // centre row
+            if (MODE == MODE_EDGE) In::load(QE + ((size_t)b[j] * N + n[j]) * ld + col[j], en[j]);
         }
 #pragma unroll
         for (int j = 0; j < UF; ++j) {
@@ -192,7 +195,8 @@ __global__ __launch_bounds__(256) void rowcombine_fwd_kernel(
 #pragma unroll
                 for (int i = 0; i < NE; ++i) {
                     const float d = en[j][i] - q[j][i];
-                    u[j][i] = u[j][i] + (d > 0.0f ? d : d * slope);
+                    const float a = u[j][i] > 0.0f ? u[j][i] : u[j][i] * slope_u;
+                    u[j][i] = a + (d > 0.0f ? d : d * slope);
                 }
             }
             if (TPG_RC_NT_STORE) Out::store_stream(out + (size_t)row[j] * C + col[j], u[j]);
@@ -210,7 +214,9 @@ template <typename TI, typename TG, int MODE>
 __global__ __launch_bounds__(256) void rowcombine_bwd_kernel(
     const TG *__restrict__ gout, const int32_t *__restrict__ idx, const int32_t *__restrict__ offs,
     const int32_t *__restrict__ list, const TI *__restrict__ E, int N, int S, int K, int C, float slope,
-    TI *__restrict__ gU, TI *__restrict__ gE, unsigned total) {
+    TI *__restrict__ gU, TI *__restrict__ gE, unsigned total, int ld, const TI *__restrict__ Uraw, float slope_u) {
+    // ld: row stride of E / gU / gE (and Uraw) in elements; Uraw (EDGE, may be NULL): the forward's U rows before
+    // their LeakyReLU(slope_u) -- gU is then the gradient of those raw rows
     constexpr int NE = Elems<TI, TG>::NE;
     using In = RowIO<TI, NE>;
     using Gr = RowIO<TG, NE>;
@@ -227,7 +233,7 @@ __global__ __launch_bounds__(256) void rowcombine_bwd_kernel(
         float acc[NE], accE[NE], en[NE];
 #pragma unroll
         for (int i = 0; i < NE; ++i) { acc[i] = 0.0f; accE[i] = 0.0f; }
-        if (MODE == MODE_EDGE) In::load(E + (size_t)drow * C + col, en);
+        if (MODE == MODE_EDGE) In::load(E + (size_t)drow * ld + col, en);
         const int p1 = of[n + 1];
         int p = of[n];
         // entries four at a time: the 4 list reads, then the 4 (+4) row reads are independent
@@ -240,7 +246,7 @@ __global__ __launch_bounds__(256) void rowcombine_bwd_kernel(
 #pragma unroll
             for (int u = 0; u < 4; ++u) {
                 Gr::load(go + (size_t)e[u] * C, g[u]);
-                if (MODE == MODE_EDGE) In::load(E + ((size_t)b * N + (unsigned)e[u] / (unsigned)K) * C + col, es[u]);
+                if (MODE == MODE_EDGE) In::load(E + ((size_t)b * N + (unsigned)e[u] / (unsigned)K) * ld + col, es[u]);
             }
 #pragma unroll
             for (int u = 0; u < 4; ++u) {
@@ -260,7 +266,7 @@ __global__ __launch_bounds__(256) void rowcombine_bwd_kernel(
             for (int i = 0; i < NE; ++i) acc[i] += g[i];
             if (MODE == MODE_EDGE) {
                 float es[NE];
-                In::load(E + ((size_t)b * N + (unsigned)e / (unsigned)K) * C + col, es);
+                In::load(E + ((size_t)b * N + (unsigned)e / (unsigned)K) * ld + col, es);
 #pragma unroll
                 for (int i = 0; i < NE; ++i) accE[i] += (en[i] - es[i] > 0.0f) ? g[i] : g[i] * slope;
             }
@@ -276,7 +282,7 @@ __global__ __launch_bounds__(256) void rowcombine_bwd_kernel(
 #pragma unroll
                 for (int u = 0; u < 4; ++u) {
                     Gr::load(go + ((size_t)n * K + k + u) * C, g[u]);
-                    In::load(E + ((size_t)b * N + nb[u]) * C + col, eb[u]);
+                    In::load(E + ((size_t)b * N + nb[u]) * ld + col, eb[u]);
                 }
 #pragma unroll
                 for (int u = 0; u < 4; ++u)
@@ -288,13 +294,19 @@ __global__ __launch_bounds__(256) void rowcombine_bwd_kernel(
                 const int nb = tpg_clamp_idx(idx[(size_t)b * SK + e], N);
                 float g[NE], eb[NE];
                 Gr::load(go + e * C, g);
-                In::load(E + ((size_t)b * N + nb) * C + col, eb);
+                In::load(E + ((size_t)b * N + nb) * ld + col, eb);
 #pragma unroll
                 for (int i = 0; i < NE; ++i) accE[i] -= (eb[i] - en[i] > 0.0f) ? g[i] : g[i] * slope;
             }
-            In::store(gE + (size_t)drow * C + col, accE);
+            In::store(gE + (size_t)drow * ld + col, accE);
+            if (Uraw) {
+                float a[NE];
+                In::load(Uraw + (size_t)drow * ld + col, a);
+#pragma unroll
+                for (int i = 0; i < NE; ++i) acc[i] = a[i] > 0.0f ? acc[i] : acc[i] * slope_u;
+            }
         }
-        In::store(gU + (size_t)drow * C + col, acc);
+        In::store(gU + (size_t)drow * ld + col, acc);
     }
 }
 
@@ -311,7 +323,7 @@ template <typename TI, typename TG, int MODE>
 __global__ __launch_bounds__(256) void rowcombine_bwd_wave_kernel(
     const TG *__restrict__ gout, const int32_t *__restrict__ idx, const int32_t *__restrict__ offs,
     const int32_t *__restrict__ list, const TI *__restrict__ E, int N, int S, int K, int C, float slope,
-    TI *__restrict__ gU, TI *__restrict__ gE, unsigned rows) {
+    TI *__restrict__ gU, TI *__restrict__ gE, unsigned rows, int ld, const TI *__restrict__ Uraw, float slope_u) {
     constexpr int NE = Elems<TI, TG>::NE;
     using In = RowIO<TI, NE>;
     using Gr = RowIO<TG, NE>;
@@ -331,7 +343,7 @@ __global__ __launch_bounds__(256) void rowcombine_bwd_wave_kernel(
         float acc[NE], accE[NE], en[NE];
 #pragma unroll
         for (int i = 0; i < NE; ++i) { acc[i] = 0.0f; accE[i] = 0.0f; }
-        if (MODE == MODE_EDGE) In::load(E + (size_t)drow * C + col, en);
+        if (MODE == MODE_EDGE) In::load(E + (size_t)drow * ld + col, en);
         const int p1 = of[n + 1];
         int p = of[n] + (int)grp;
         // two entries per lane group in flight
@@ -342,8 +354,8 @@ __global__ __launch_bounds__(256) void rowcombine_bwd_wave_kernel(
             Gr::load(go + (size_t)e1 * C, g1);
             if (MODE == MODE_EDGE) {
                 float s0[NE], s1[NE];
-                In::load(E + ((size_t)b * N + (unsigned)e0 / (unsigned)K) * C + col, s0);
-                In::load(E + ((size_t)b * N + (unsigned)e1 / (unsigned)K) * C + col, s1);
+                In::load(E + ((size_t)b * N + (unsigned)e0 / (unsigned)K) * ld + col, s0);
+                In::load(E + ((size_t)b * N + (unsigned)e1 / (unsigned)K) * ld + col, s1);
 #pragma unroll
                 for (int i = 0; i < NE; ++i) {
                     accE[i] += (en[i] - s0[i] > 0.0f) ? g0[i] : g0[i] * slope;
@@ -361,7 +373,7 @@ __global__ __launch_bounds__(256) void rowcombine_bwd_wave_kernel(
             for (int i = 0; i < NE; ++i) acc[i] += g0[i];
             if (MODE == MODE_EDGE) {
                 float s0[NE];
-                In::load(E + ((size_t)b * N + (unsigned)e0 / (unsigned)K) * C + col, s0);
+                In::load(E + ((size_t)b * N + (unsigned)e0 / (unsigned)K) * ld + col, s0);
 #pragma unroll
                 for (int i = 0; i < NE; ++i) accE[i] += (en[i] - s0[i] > 0.0f) ? g0[i] : g0[i] * slope;
             }
@@ -373,7 +385,7 @@ __global__ __launch_bounds__(256) void rowcombine_bwd_wave_kernel(
                 const int nb = tpg_clamp_idx(idx[(size_t)b * SK + e], N);
                 float g0[NE], eb[NE];
                 Gr::load(go + e * C, g0);
-                In::load(E + ((size_t)b * N + nb) * C + col, eb);
+                In::load(E + ((size_t)b * N + nb) * ld + col, eb);
 #pragma unroll
                 for (int i = 0; i < NE; ++i) accE[i] -= (eb[i] - en[i] > 0.0f) ? g0[i] : g0[i] * slope;
             }
@@ -387,8 +399,16 @@ __global__ __launch_bounds__(256) void rowcombine_bwd_wave_kernel(
             }
         }
         if (grp == 0) {
-            if (MODE == MODE_EDGE) In::store(gE + (size_t)drow * C + col, accE);
-            In::store(gU + (size_t)drow * C + col, acc);
+            if (MODE == MODE_EDGE) {
+                In::store(gE + (size_t)drow * ld + col, accE);
+                if (Uraw) {
+                    float a[NE];
+                    In::load(Uraw + (size_t)drow * ld + col, a);
+#pragma unroll
+                    for (int i = 0; i < NE; ++i) acc[i] = a[i] > 0.0f ? acc[i] : acc[i] * slope_u;
+                }
+            }
+            In::store(gU + (size_t)drow * ld + col, acc);
         }
     }
 }
@@ -438,7 +458,7 @@ bool dtype_ok(int d) { return d == TPG_DTYPE_F32 || d == TPG_DTYPE_BF16; }
 
 template <typename TI, typename TO>
 int fwd_go(const void *U, const void *QE, const int32_t *idx, int mode, int B, int N, int S, int K,
-           int C, float slope, void *out, hipStream_t st) {
+           int C, float slope, void *out, hipStream_t st, int ld, float slope_u) {
     constexpr int NE = Elems<TI, TO>::NE;
     if (C % NE) return TPG_ERR_UNSUPPORTED;
     const unsigned long long total64 = (unsigned long long)B * S * K * (C / NE);
@@ -452,17 +472,18 @@ int fwd_go(const void *U, const void *QE, const int32_t *idx, int mode, int B, i
     const TI *u = static_cast<const TI *>(U), *q = static_cast<const TI *>(QE);
     TO *o = static_cast<TO *>(out);
     if (mode == MODE_GATHER)
-        hipLaunchKernelGGL((rowcombine_fwd_kernel<TI, TO, MODE_GATHER>), g, blk, 0, st, u, q, idx, N, S, K, C, slope, o, total, xo);
+        hipLaunchKernelGGL((rowcombine_fwd_kernel<TI, TO, MODE_GATHER>), g, blk, 0, st, u, q, idx, N, S, K, C, slope, o, total, xo, ld, slope_u);
     else if (mode == MODE_SUB)
-        hipLaunchKernelGGL((rowcombine_fwd_kernel<TI, TO, MODE_SUB>), g, blk, 0, st, u, q, idx, N, S, K, C, slope, o, total, xo);
+        hipLaunchKernelGGL((rowcombine_fwd_kernel<TI, TO, MODE_SUB>), g, blk, 0, st, u, q, idx, N, S, K, C, slope, o, total, xo, ld, slope_u);
     else
-        hipLaunchKernelGGL((rowcombine_fwd_kernel<TI, TO, MODE_EDGE>), g, blk, 0, st, u, q, idx, N, S, K, C, slope, o, total, xo);
+        hipLaunchKernelGGL((rowcombine_fwd_kernel<TI, TO, MODE_EDGE>), g, blk, 0, st, u, q, idx, N, S, K, C, slope, o, total, xo, ld, slope_u);
     return TPG_OK;
 }
 
 template <typename TI, typename TG>
 int bwd_go(const void *gout, const int32_t *idx, const int32_t *offs, const int32_t *list, const void *E,
-           int mode, int B, int N, int S, int K, int C, float slope, void *gU, void *gQE, hipStream_t st) {
+           int mode, int B, int N, int S, int K, int C, float slope, void *gU, void *gQE, hipStream_t st, int ld,
+           const void *Uraw, float slope_u) {
     constexpr int NE = Elems<TI, TG>::NE;
     if (C % NE) return TPG_ERR_UNSUPPORTED;
     const unsigned long long total64 = (unsigned long long)B * N * (C / NE);
@@ -473,6 +494,7 @@ int bwd_go(const void *gout, const int32_t *idx, const int32_t *offs, const int3
     const TG *go = static_cast<const TG *>(gout);
     const TI *e = static_cast<const TI *>(E);
     TI *gu = static_cast<TI *>(gU), *gq = static_cast<TI *>(gQE);
+    const TI *ur = static_cast<const TI *>(Uraw);
     const unsigned cpr = (unsigned)(C / NE);
 #ifndef TPG_RC_BWD_THREAD_PER_ROW
     // a wave per row needs >= 2 lane groups; for the generator's 16-channel EDGE rows (two chunks per row, ~k entries
@@ -487,14 +509,14 @@ int bwd_go(const void *gout, const int32_t *idx, const int32_t *offs, const int3
     const dim3 gw(wgs > TPG_RC_BWD_WAVE_CAP ? TPG_RC_BWD_WAVE_CAP : wgs);
     if (mode == MODE_EDGE) {
         if (by_wave)
-            hipLaunchKernelGGL((rowcombine_bwd_wave_kernel<TI, TG, MODE_EDGE>), gw, blk, 0, st, go, idx, offs, list, e, N, S, K, C, slope, gu, gq, rows);
+            hipLaunchKernelGGL((rowcombine_bwd_wave_kernel<TI, TG, MODE_EDGE>), gw, blk, 0, st, go, idx, offs, list, e, N, S, K, C, slope, gu, gq, rows, ld, ur, slope_u);
         else
-            hipLaunchKernelGGL((rowcombine_bwd_kernel<TI, TG, MODE_EDGE>), g, blk, 0, st, go, idx, offs, list, e, N, S, K, C, slope, gu, gq, total);
+            hipLaunchKernelGGL((rowcombine_bwd_kernel<TI, TG, MODE_EDGE>), g, blk, 0, st, go, idx, offs, list, e, N, S, K, C, slope, gu, gq, total, ld, ur, slope_u);
     } else {
         if (by_wave)
-            hipLaunchKernelGGL((rowcombine_bwd_wave_kernel<TI, TG, MODE_GATHER>), gw, blk, 0, st, go, idx, offs, list, e, N, S, K, C, slope, gu, gq, rows);
+            hipLaunchKernelGGL((rowcombine_bwd_wave_kernel<TI, TG, MODE_GATHER>), gw, blk, 0, st, go, idx, offs, list, e, N, S, K, C, slope, gu, gq, rows, ld, ur, slope_u);
         else
-            hipLaunchKernelGGL((rowcombine_bwd_kernel<TI, TG, MODE_GATHER>), g, blk, 0, st, go, idx, offs, list, e, N, S, K, C, slope, gu, gq, total);
+            hipLaunchKernelGGL((rowcombine_bwd_kernel<TI, TG, MODE_GATHER>), g, blk, 0, st, go, idx, offs, list, e, N, S, K, C, slope, gu, gq, total, ld, ur, slope_u);
         if (mode == MODE_SUB) {
             const unsigned totq = (unsigned)totq64;
             hipLaunchKernelGGL((rowsum_neg_kernel<TI, TG>), dim3(grid_for(totq)), blk, 0, st, go, K, C, gq, totq);
@@ -519,7 +541,7 @@ extern "C" int tpg_rowcombine_fwd(const void *U, const void *QE, const int32_t *
     if (mode == MODE_EDGE && S != N) return TPG_ERR_ARG;
     if (!dtype_ok(dtype_in) || !dtype_ok(dtype_out) || !aligned16(U, QE, out, nullptr)) return TPG_ERR_UNSUPPORTED;
     hipStream_t st = tpg_stream(stream);
-#define TPG_FWD(TI, TO) fwd_go<TI, TO>(U, QE, idx, mode, B, N, S, K, C, slope, out, st)
+#define TPG_FWD(TI, TO) fwd_go<TI, TO>(U, QE, idx, mode, B, N, S, K, C, slope, out, st, C, 1.0f)
     const int rc = TPG_DISPATCH2(dtype_in, dtype_out, TPG_FWD);
 #undef TPG_FWD
     if (rc) return rc;
@@ -549,7 +571,52 @@ extern "C" int tpg_rowcombine_bwd(const void *gout, const int32_t *idx, const in
     if (mode == MODE_SUB && !gQE) return TPG_ERR_ARG;
     if (!dtype_ok(dtype_in) || !dtype_ok(dtype_out) || !aligned16(gout, gU, gQE, E)) return TPG_ERR_UNSUPPORTED;
     hipStream_t st = tpg_stream(stream);
-#define TPG_BWD(TI, TG) bwd_go<TI, TG>(gout, idx, offs, list, E, mode, B, N, S, K, C, slope, gU, gQE, st)
+#define TPG_BWD(TI, TG) bwd_go<TI, TG>(gout, idx, offs, list, E, mode, B, N, S, K, C, slope, gU, gQE, st, C, nullptr, 1.0f)
+    const int rc = TPG_DISPATCH2(dtype_in, dtype_out, TPG_BWD);
+#undef TPG_BWD
+    if (rc) return rc;
+    TPG_RETURN_IF_LAUNCH_FAILED();
+    return TPG_OK;
+}
+
+// EdgeConv front end on ONE product (round 3): Y (B,N,2C) = f [We; Wn]^T, columns [0,C) = E, [C,2C) = the node
+// term BEFORE its LeakyReLU.  The same kernels with a row stride of 2C and the activation of the gathered node row
+// (forward) / its derivative (backward) folded in: one GEMM, one data-gradient GEMM and one weight gradient per
+// EdgeConv instead of two each, no LeakyReLU launches, no gradient sum of the shared input.
+extern "C" int tpg_rowcombine_edge_fwd(const void *Y, const int32_t *idx, int dtype_in, int dtype_out, int B, int N,
+                                       int K, int C, float slope_a, float slope_e, void *out, void *stream) {
+    if (B < 0 || N <= 0 || K < 0 || C <= 0) return TPG_ERR_ARG;
+    if ((long long)B * N * K == 0) return TPG_OK;
+    if (!Y || !idx || !out) return TPG_ERR_ARG;
+    if (!dtype_ok(dtype_in) || !dtype_ok(dtype_out) || !aligned16(Y, out, nullptr, nullptr)) return TPG_ERR_UNSUPPORTED;
+    const int esz = dtype_in == TPG_DTYPE_F32 ? 4 : 2;
+    if (((size_t)C * esz) & 15) return TPG_ERR_UNSUPPORTED;             // the node half starts 16-byte aligned
+    const char *y = static_cast<const char *>(Y);
+    const void *A = y + (size_t)C * esz, *E = y;
+    hipStream_t st = tpg_stream(stream);
+#define TPG_FWD(TI, TO) fwd_go<TI, TO>(A, E, idx, MODE_EDGE, B, N, N, K, C, slope_e, out, st, 2 * C, slope_a)
+    const int rc = TPG_DISPATCH2(dtype_in, dtype_out, TPG_FWD);
+#undef TPG_FWD
+    if (rc) return rc;
+    TPG_RETURN_IF_LAUNCH_FAILED();
+    return TPG_OK;
+}
+
+extern "C" int tpg_rowcombine_edge_bwd(const void *gout, const int32_t *idx, const int32_t *offs, const int32_t *list,
+                                       const void *Y, int dtype_in, int dtype_out, int B, int N, int K, int C,
+                                       float slope_a, float slope_e, void *gY, void *stream) {
+    if (B < 0 || N <= 0 || K < 0 || C <= 0) return TPG_ERR_ARG;
+    if (B == 0) return TPG_OK;
+    if (!gout || !idx || !offs || !list || !Y || !gY) return TPG_ERR_ARG;
+    if (!dtype_ok(dtype_in) || !dtype_ok(dtype_out) || !aligned16(gout, gY, Y, nullptr)) return TPG_ERR_UNSUPPORTED;
+    const int esz = dtype_in == TPG_DTYPE_F32 ? 4 : 2;
+    if (((size_t)C * esz) & 15) return TPG_ERR_UNSUPPORTED;
+    const char *y = static_cast<const char *>(Y);
+    char *gy = static_cast<char *>(gY);
+    const void *A = y + (size_t)C * esz, *E = y;
+    void *gA = gy + (size_t)C * esz, *gE = gy;
+    hipStream_t st = tpg_stream(stream);
+#define TPG_BWD(TI, TG) bwd_go<TI, TG>(gout, idx, offs, list, E, MODE_EDGE, B, N, N, K, C, slope_e, gA, gE, st, 2 * C, A, slope_a)
     const int rc = TPG_DISPATCH2(dtype_in, dtype_out, TPG_BWD);
 #undef TPG_BWD
     if (rc) return rc;

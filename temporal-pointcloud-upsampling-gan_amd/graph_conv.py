@@ -20,6 +20,7 @@ Layers with batch/instance norm or spectral norm keep the reference order
 (`_forward_planes`); the generator never builds those.
 """
 import contextlib
+import os
 from typing import List
 
 import torch
@@ -226,21 +227,26 @@ class _TallLinear(torch.autograd.Function):
             dx = ops.timed("gemm_dgrad", e * P * (cin + cout), 2 * P * cin * cout, gy, lambda: gy @ wd).to(ctx.x_dtype)
         with _wgrad_ctx(gy, xd):
             if ctx.needs_input_grad[1]:
-                S = _split_k(P, wd.shape[0], wd.shape[1])
-                if S > 1:
-                    rows = P // S
-                    head = S * rows
-                    dw = ops.timed("gemm_wgrad", e * P * (cin + cout), 2 * P * cin * cout, gy,
-                                   lambda: _mm_f32(torch.bmm, gy[:head].view(S, rows, -1).transpose(1, 2),
-                                                   xd[:head].view(S, rows, -1))).sum(0)
-                    if head < P:
-                        dw = dw + _mm_f32(torch.mm, gy[head:].t(), xd[head:])
-                else:
-                    dw = _mm_f32(torch.mm, gy.t(), xd)
-                dw = dw.to(ctx.w_dtype)
+                dw = _tall_wgrad(gy, xd).to(ctx.w_dtype)
             if ctx.b_dtype is not None and ctx.needs_input_grad[2]:
                 db = gy.sum(0, dtype=torch.float32).to(ctx.b_dtype)
         return dx, dw, db, None
+
+
+def _tall_wgrad(gy, xd):
+    """dW (Cout,Cin) fp32 = gy (P,Cout)^T xd (P,Cin) as a split-K batched GEMM (see _TallLinear)."""
+    P, cout, cin, e = gy.shape[0], gy.shape[1], xd.shape[1], xd.element_size()
+    S = _split_k(P, cout, cin)
+    if S > 1:
+        rows = P // S
+        head = S * rows
+        dw = ops.timed("gemm_wgrad", e * P * (cin + cout), 2 * P * cin * cout, gy,
+                       lambda: _mm_f32(torch.bmm, gy[:head].view(S, rows, -1).transpose(1, 2),
+                                       xd[:head].view(S, rows, -1))).sum(0)
+        if head < P:
+            dw = dw + _mm_f32(torch.mm, gy[head:].t(), xd[head:])
+        return dw
+    return _mm_f32(torch.mm, gy.t(), xd)
 
 
 _F32_OUT = [None]     # does this torch build take out_dtype on mm / bmm?  (probed once, on the device)
@@ -302,6 +308,66 @@ class _TallLinearSeg(torch.autograd.Function):
                     dw = dw + _mm_f32(torch.bmm, gy[:, head:].transpose(1, 2), xd[:, head:])
                 dw = dw.to(ctx.w_dtype)
         return dx, dw, None
+
+
+def _stacked_weight(we, wn):
+    """[We; Wn] as ONE (2H, Cin) matrix: a view when the two matrices sit back to back in one allocation (a step that
+    keeps its parameters in a flat buffer has them in registration order, edge_affine right before node_affine), else
+    their concatenation (one launch)."""
+    if (we.shape == wn.shape and we.dtype == wn.dtype and we.is_contiguous() and wn.is_contiguous()
+            and wn.data_ptr() == we.data_ptr() + we.numel() * we.element_size()
+            and we.untyped_storage().data_ptr() == wn.untyped_storage().data_ptr()):
+        return we.as_strided((2 * we.shape[0], we.shape[1]), (we.shape[1], 1), we.storage_offset())
+    return torch.cat([we, wn], 0)
+
+
+EDGE_FRONT = [os.environ.get("TPGAN_EDGE_FRONT", "1") != "0"]     # EdgeConv front end on one product (off: two GEMMs + LeakyReLU + ops.row_combine, for A/B runs)
+
+
+class _EdgeFront(torch.autograd.Function):
+    """h[b,n,k,:] = lrelu(Wn f[idx]) + lrelu(We f[idx] - We f[n]) of an EdgeConv (gcn.py:176-180,207-210) from ONE
+    product Y = f [We; Wn]^T (csrc/rowgather.hip, tpg_rowcombine_edge_*): one GEMM, one data-gradient GEMM and one
+    split-K weight gradient instead of two each, the node term's LeakyReLU and its derivative inside the gather
+    kernels, no gradient sum of the shared input -- 7 launches fewer per EdgeConv and step on a latency-bound chain."""
+
+    @staticmethod
+    def forward(ctx, x, we, wn, idx, slope_a, slope_e, out_dtype, inverse):
+        B, N, cin = x.shape
+        H = we.shape[0]
+        P = B * N
+        wc = _stacked_weight(we.detach(), wn.detach())
+        xr = x.reshape(P, cin)
+        Y = ops.timed("gemm_fwd", 4 * P * (cin + 2 * H), 4 * P * cin * H, xr, lambda: xr @ wc.t()).view(B, N, 2 * H)
+        h = ops.backend_for(x).rowcombine_edge_fwd(Y, idx, slope_a, slope_e, out_dtype)
+        ctx.save_for_backward(xr, wc, Y, idx)
+        ctx.inverse, ctx.slopes, ctx.shape = inverse, (slope_a, slope_e), (B, N, cin, H)
+        return h
+
+    @staticmethod
+    def backward(ctx, gh):
+        xr, wc, Y, idx = ctx.saved_tensors
+        B, N, cin, H = ctx.shape
+        P = B * N
+        gh = gh.contiguous()
+        if gh.dtype not in (torch.float32, torch.bfloat16):
+            gh = gh.float()
+        kw = {} if ctx.inverse is None else {"inverse": ctx.inverse}
+        gY = ops.backend_for(gh).rowcombine_edge_bwd(gh, idx, Y, ctx.slopes[0], ctx.slopes[1], **kw).view(P, 2 * H)
+        dx = dwe = dwn = None
+        if ctx.needs_input_grad[0]:
+            dx = ops.timed("gemm_dgrad", 4 * P * (cin + 2 * H), 4 * P * cin * H, gY, lambda: gY @ wc).view(B, N, cin)
+        if ctx.needs_input_grad[1] or ctx.needs_input_grad[2]:
+            with _wgrad_ctx(gY, xr):
+                dw = _tall_wgrad(gY, xr)
+            dwe, dwn = dw[:H], dw[H:]
+        return dx, dwe, dwn, None, None, None, None, None
+
+
+def edge_front(x, we, wn, idx, slope_a, slope_e, out_dtype):
+    """x (B,N,Cin) fp32 rows, we / wn (H,Cin) the bare edge / node convolutions, idx (B,N,K) int32 -> (B,N,K,H)."""
+    inv = getattr(idx, "_tpg_inverse", None)
+    inverse = inv[1:] if inv is not None and inv[0] == x.shape[1] else None
+    return _EdgeFront.apply(x.contiguous(), we, wn, idx, float(slope_a), float(slope_e), out_dtype, inverse)
 
 
 def _act(y, slope):
@@ -480,11 +546,18 @@ class EdgeConv(nn.Module):
             idx = g._dilated(knn_idx[:, :, :g.k]).to(torch.int32).contiguous()
         else:
             idx = self.dilated_knn_graph(pos if pos is not None else x).to(torch.int32).contiguous()
-        with no_autocast(x):
-            xf = x.float()
-            A = rows_linear(self.node_affine[0], xf, 0.2)                # (B,N,H), LeakyReLU in the epilogue
-            E = rows_linear(self.edge_affine[0], xf)
-        h = ops.row_combine(A, E, idx, ops.ROW_EDGE, slope=0.2, out_dtype=amp_dtype(x))   # (B,N,k,H)
+        na, ea = self.node_affine[0], self.edge_affine[0]
+        H = na.out_channels
+        if (EDGE_FRONT[0] and na.bias is None and ea.bias is None and H == ea.out_channels
+                and H % (4 if amp_dtype(x) == torch.float32 else 8) == 0):
+            with no_autocast(x):                                         # one product for both terms (_EdgeFront)
+                h = edge_front(x.float(), ea.weight.view(H, -1), na.weight.view(H, -1), idx, 0.2, 0.2, amp_dtype(x))
+        else:
+            with no_autocast(x):
+                xf = x.float()
+                A = rows_linear(na, xf, 0.2)                             # (B,N,H), LeakyReLU in the epilogue
+                E = rows_linear(ea, xf)
+            h = ops.row_combine(A, E, idx, ops.ROW_EDGE, slope=0.2, out_dtype=amp_dtype(x))   # (B,N,k,H)
         if self.mlp_layer:
             mods = list(self.mlp)
             C_out = mods[-2].out_channels if isinstance(mods[-2], nn.Conv2d) else 0

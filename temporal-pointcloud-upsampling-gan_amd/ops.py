@@ -367,6 +367,29 @@ class HipBackend:
         return gU, gQE
 
 
+    def rowcombine_edge_fwd(self, Y, idx, slope_a, slope_e, out_dtype):
+        """Y (B,N,2C) = f [We; Wn]^T -> lrelu(Y[idx, C:], slope_a) + lrelu(Y[idx, :C] - Y[n, :C], slope_e), (B,N,K,C)."""
+        B, N, C2 = Y.shape
+        Cc, K = C2 // 2, idx.shape[2]
+        out = torch.empty((B, N, K, Cc), dtype=out_dtype, device=Y.device)
+        nbytes = Y.element_size() * B * N * C2 + 4 * B * N * K + out.element_size() * B * N * K * Cc
+        self._call("tpg_rowcombine_edge_fwd", "rowcombine_fwd", nbytes, Y,
+                   _ptr(Y), _ptr(idx), _DTYPE_CODE[Y.dtype], _DTYPE_CODE[out_dtype], B, N, K, Cc, float(slope_a),
+                   float(slope_e), _ptr(out))
+        return out
+
+    def rowcombine_edge_bwd(self, gout, idx, Y, slope_a, slope_e, inverse=None):
+        B, N, K, Cc = gout.shape
+        if inverse is None:
+            inverse = self.invert_index(idx, N)
+        offs, lst = inverse
+        gY = torch.empty_like(Y)
+        nbytes = gout.element_size() * B * N * K * Cc * 2 + 8 * B * N * K + 2 * Y.element_size() * B * N * 2 * Cc
+        self._call("tpg_rowcombine_edge_bwd", "rowcombine_bwd", nbytes, gout,
+                   _ptr(gout), _ptr(idx), _ptr(offs), _ptr(lst), _ptr(Y), _DTYPE_CODE[Y.dtype], _DTYPE_CODE[gout.dtype],
+                   B, N, K, Cc, float(slope_a), float(slope_e), _ptr(gY))
+        return gY
+
     # ---- fused BatchNorm + LeakyReLU (+ max over K) on rows (csrc/rowbn.hip) -------------
     def _bn_ws(self, x, C_, nseg=1):
         # one scratch buffer per (device, stream), reused by every call: launches on a stream are

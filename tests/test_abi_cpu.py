@@ -103,6 +103,14 @@ def test_new_entries_reject_bad_arguments_before_any_launch(hip_lib):
     assert hip_lib.tpg_mlp_bn_bwd_apply_rowsum(p, p, p, p, 64, 0, 64, 1, p, p, None) == -1
     assert hip_lib.tpg_mlp_bn_bwd_apply_rowsum(p, p, p, p, 64, 8, 64, 1, p, None, None) == -1
     assert hip_lib.tpg_mlp_bn_bwd_apply_rowsum(p, p, p, p, 64, 8, 60, 1, p, p, None) == -3
+    # EdgeConv front end on one product (round 3): the node half must start 16-byte aligned, both halves present
+    assert hip_lib.tpg_rowcombine_edge_fwd(p, p, 0, 0, 1, 8, 4, 6, 0.2, 0.2, p, None) == -3      # C = 6 floats
+    assert hip_lib.tpg_rowcombine_edge_fwd(None, p, 0, 0, 1, 8, 4, 8, 0.2, 0.2, p, None) == -1
+    assert hip_lib.tpg_rowcombine_edge_fwd(p, p, 0, 0, 0, 8, 4, 8, 0.2, 0.2, p, None) == 0
+    assert hip_lib.tpg_rowcombine_edge_fwd(p, p, 2, 0, 1, 8, 4, 8, 0.2, 0.2, p, None) == -3      # unknown dtype
+    assert hip_lib.tpg_rowcombine_edge_bwd(p, p, p, p, None, 0, 0, 1, 8, 4, 8, 0.2, 0.2, p, None) == -1
+    assert hip_lib.tpg_rowcombine_edge_bwd(p, p, p, p, p, 0, 0, 1, 8, 4, 8, 0.2, 0.2, None, None) == -1
+    assert hip_lib.tpg_rowcombine_edge_bwd(p, p, p, p, p, 0, 0, 1, 8, 4, 6, 0.2, 0.2, p, None) == -3
     # statistics / backward sums with the folded constants from the same finalize launch
     assert hip_lib.tpg_rowbn_stats_consts(p, 1, 64, 64, 1e-5, 0.1, None, None, None, None, p, p, p, p, None, p, 1, None) == -1
     assert hip_lib.tpg_rowbn_stats_consts(p, 1, 64, 60, 1e-5, 0.1, None, None, None, None, p, p, p, p, p, p, 1, None) == -3

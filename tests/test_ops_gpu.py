@@ -429,6 +429,69 @@ def test_rowcombine_fwd_exact_bwd_close(hip, mode, B, N, S, K, C, din, dout):
         assert gQ is None
 
 
+@pytest.mark.parametrize("B,N,K,C", [(2, 512, 20, 64), (3, 512, 10, 16), (1, 100, 7, 8), (2, 1024, 12, 128), (1, 4096, 4, 128)])
+@pytest.mark.parametrize("din,dout", [("f32", "f32"), ("f32", "bf16"), ("bf16", "bf16")])
+def test_rowcombine_edge_front_fwd_exact_bwd_close(hip, B, N, K, C, din, dout):
+    """tpg_rowcombine_edge_fwd / _bwd (the EdgeConv front end on one product, Y = f [We; Wn]^T) against the oracle:
+    forward bit-exact (same fp32 arithmetic, one rounding on store), backward to summation order; the shapes are the
+    generator's EdgeConvs (H = 64 k = 20, H = 16 k = 20 / 10, H = 128 k = 12 / 8 / 4) and a ragged one."""
+    tdt = {"f32": torch.float32, "bf16": torch.bfloat16}
+    rng = np.random.default_rng(K * 31 + C)
+    Y = rng.standard_normal((B, N, 2 * C)).astype(np.float32)
+    idx = rng.integers(0, N, (B, N, K)).astype(np.int32)
+    idx[0, 0, :] = 3
+    idx[B - 1, :, 0] = 5                  # a hub row
+    if din == "bf16":
+        Y = _bf16_round(Y)
+    Yd = dev(Y).to(tdt[din])
+    out = hip.rowcombine_edge_fwd(Yd, dev(idx), 0.2, 0.1, tdt[dout])
+    ref = R.rowcombine_edge_fwd(Y, idx, 0.2, 0.1)
+    if dout == "bf16":
+        ref = _bf16_round(ref)
+    assert out.dtype == tdt[dout] and out.shape == (B, N, K, C)
+    assert np.array_equal(out.float().cpu().numpy(), ref)
+    g = rng.standard_normal((B, N, K, C)).astype(np.float32)
+    if dout == "bf16":
+        g = _bf16_round(g)
+    gY = hip.rowcombine_edge_bwd(dev(g).to(tdt[dout]), dev(idx), Yd, 0.2, 0.1)
+    rY = R.rowcombine_edge_bwd(g, idx, Y, 0.2, 0.1)
+    tol = TOL if din == "f32" else 1e-2
+    assert gY.dtype == tdt[din] and gY.shape == (B, N, 2 * C)
+    assert np.abs(gY.float().cpu().numpy() - rY).max() <= tol * max(1.0, np.abs(rY).max())
+    # and bitwise reproducible (ordered sums over the radix-sorted inverted index)
+    gY2 = hip.rowcombine_edge_bwd(dev(g).to(tdt[dout]), dev(idx), Yd, 0.2, 0.1)
+    assert torch.equal(gY, gY2)
+
+
+@pytest.mark.parametrize("cin,H,K,flat", [(3, 64, 20, False), (32, 16, 10, True), (64, 128, 12, True)])
+def test_edge_front_function_equals_two_products(hip, cin, H, K, flat):
+    """graph_conv.edge_front (one GEMM + tpg_rowcombine_edge_*) against the form it replaces -- two GEMMs, LeakyReLU,
+    ops.row_combine(ROW_EDGE) -- outputs and all three gradients; `flat`: the two weights back to back in one buffer
+    (the stacked weight is then a view, as inside the graphed step)."""
+    from tpgan_amd import graph_conv, ops
+    torch.manual_seed(cin + H)
+    B, N = 2, 512
+    x = torch.randn(B, N, cin, device="cuda", requires_grad=True)
+    if flat:
+        buf = torch.randn(2 * H * cin, device="cuda") * 0.3
+        we, wn = buf[:H * cin].view(H, cin), buf[H * cin:].view(H, cin)
+        assert graph_conv._stacked_weight(we, wn).data_ptr() == buf.data_ptr()
+    else:
+        we, wn = torch.randn(H, cin, device="cuda") * 0.3, torch.randn(H, cin, device="cuda") * 0.3
+    we, wn = we.detach().requires_grad_(), wn.detach().requires_grad_()
+    idx = torch.randint(0, N, (B, N, K), device="cuda", dtype=torch.int32)
+    g = torch.randn(B, N, K, H, device="cuda")
+    h = graph_conv.edge_front(x, we, wn, idx, 0.2, 0.2, torch.float32)
+    gx, gwe, gwn = torch.autograd.grad(h, [x, we, wn], g)
+    A = torch.nn.functional.leaky_relu(x @ wn.t(), 0.2)
+    E = x @ we.t()
+    h0 = ops.row_combine(A, E, idx, ops.ROW_EDGE, slope=0.2, out_dtype=torch.float32)
+    rx, rwe, rwn = torch.autograd.grad(h0, [x, we, wn], g)
+    assert (h - h0).abs().max() <= 1e-5 * max(1.0, h0.abs().max())
+    for a, b in ((gx, rx), (gwe, rwe), (gwn, rwn)):
+        assert (a - b).abs().max() <= 2e-5 * max(1.0, b.abs().max())
+
+
 @pytest.mark.parametrize("N,SK", [(1000, 7777), (16384, 4096 * 32), (16352, 5000), (16353, 5000),
                                   (40928, 70001), (100000, 150000), (200, 999), (256, 64), (257, 1), (2, 5000),
                                   (1, 130), (4096, 81920), (512, 512 * 20), (32704, 3000), (32705, 3000),
