@@ -356,6 +356,18 @@ int tpg_spectral_norm_bwd(const float *G, const float *Wsn, const float *u, cons
 long long tpg_spectral_norm_multi_stride(int R, int Cn);
 int tpg_spectral_norm_multi_fwd(const void *desc, int M, int max_rc, float *out, int iterate, float eps,
                                 void *stream);
+/* The same forward in TRAINING mode with every weight's rows split over ceil(R / tpg_spectral_norm_split_rows())
+ * workgroups that keep their rows in registers for all uses and exchange partial column sums once per use (round 3:
+ * the one-workgroup form is the longest launch at the head of the temporal discriminator's update).  Same output layout.
+ * desc: per weight 9 x int64 {W, u, v, R, Cn, uses, out_off, parts, x_off}; x_off = offset, in 8-byte words, of the
+ * weight's 2 * parts * (Cn + 1) exchange words inside xws.  part_map: total_parts x int32[2] = (weight, part).
+ * xws: xws_words 8-byte words, 16-byte aligned (the exchange words of all weights + one trailing word that is non-zero
+ * after the launch if a bounded spin gave up); zeroed by the call itself.  Cn <= tpg_spectral_norm_split_max_cn(). */
+int tpg_spectral_norm_multi_fwd_split(const void *desc, const void *part_map, int total_parts, int max_cn, float *out,
+                                      void *xws, long long xws_words, float eps, void *stream);
+int tpg_spectral_norm_split_rows(void);
+int tpg_spectral_norm_split_max_cn(void);
+int tpg_spectral_norm_split_max_rows(void);      /* R <= this (at most 16 workgroups per weight) */
 /* backward: max_uses = max over m of uses (<= 64); scratch: tpg_spectral_norm_multi_bwd_scratch(M, max_uses)
  * floats (the partial inner products <G_t, Wsn_t> of the row chunks, summed in fixed order). */
 long long tpg_spectral_norm_multi_bwd_scratch(int M, int max_uses);

@@ -47,6 +47,7 @@ SIGNATURES = {
     "tpg_spectral_norm_fwd": [_P, _P, _P, _I, _I, _I, _F, _P, _P, _P],
     "tpg_spectral_norm_bwd": [_P, _P, _P, _P, _P, _I, _I, _P, _P],
     "tpg_spectral_norm_multi_fwd": [_P, _I, _I, _P, _I, _F, _P],
+    "tpg_spectral_norm_multi_fwd_split": [_P, _P, _I, _I, _P, _P, _L, _F, _P],
     "tpg_spectral_norm_multi_bwd": [_P, _I, _I, _P, _P, _P, _P, _P],
     "tpg_rowbn_bwd_sums": [_P, _I, _P, _I, _P, _P, _I, _L, _I, _I, _I, _P, _P, _P, _P, _F, _P, _P, _P, _P, _I, _P],
     "tpg_rowbn_bwd_sums_consts": [_P, _I, _P, _I, _P, _P, _I, _L, _I, _I, _I, _P, _P, _P, _P, _F, _P, _P, _P, _P, _P, _P, _I, _P],
@@ -67,7 +68,8 @@ SIGNATURES = {
 SIZE_GETTERS = ("tpg_rowbn_workspace_bytes", "tpg_mlp_workspace_bytes")
 OTHER_GETTERS = ("tpg_spectral_norm_multi_stride", "tpg_spectral_norm_multi_bwd_scratch",
                  "tpg_mlp_wgrad_workspace_bytes", "tpg_frnn_grid_workspace_bytes", "tpg_small_tail_workspace_bytes",
-                 "tpg_chamfer_bwd_workspace_bytes", "tpg_rowlinear_wgrad_workspace_bytes", "tpg_rowlinear_supported")
+                 "tpg_chamfer_bwd_workspace_bytes", "tpg_rowlinear_wgrad_workspace_bytes", "tpg_rowlinear_supported",
+                 "tpg_spectral_norm_split_rows", "tpg_spectral_norm_split_max_cn", "tpg_spectral_norm_split_max_rows")
 STRING_GETTERS = ("tpg_version", "tpg_target_arch")
 
 STATUS = {0: "TPG_OK", -1: "TPG_ERR_ARG", -2: "TPG_ERR_LAUNCH", -3: "TPG_ERR_UNSUPPORTED"}
@@ -112,6 +114,9 @@ def load():
     lib.tpg_chamfer_bwd_workspace_bytes.restype = C.c_size_t
     lib.tpg_rowlinear_wgrad_workspace_bytes.argtypes = [C.c_longlong, C.c_int, C.c_int, C.c_int, C.c_int]
     lib.tpg_rowlinear_wgrad_workspace_bytes.restype = C.c_size_t
+    for name in ("tpg_spectral_norm_split_rows", "tpg_spectral_norm_split_max_cn", "tpg_spectral_norm_split_max_rows"):
+        getattr(lib, name).argtypes = []
+        getattr(lib, name).restype = C.c_int
     lib.tpg_rowlinear_supported.argtypes = [C.c_int, C.c_int, C.c_int]
     lib.tpg_rowlinear_supported.restype = C.c_int
     _lib = lib

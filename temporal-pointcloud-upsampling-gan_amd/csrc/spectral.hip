@@ -213,6 +213,270 @@ __global__ __launch_bounds__(SN_THREADS) void spectral_norm_multi_fwd_kernel(con
     }
 }
 
+// ---- split form (round 3): a weight's rows over several workgroups ---------------------------
+// The one-workgroup form above pulls every use's three passes over a 0.5 MB weight through ONE CU: 165 us per launch
+// at cfg2 (280 us for the temporal update's six chained uses, at the head of the chain that ends the step), 513 us at
+// cfg4.  Here a workgroup of four waves owns 32 rows of a weight IN REGISTERS (8 rows x <= 576 columns per wave: the
+// weight is read from memory once for all uses) and the ceil(R / 32) workgroups of a weight exchange, once per use,
+// their partial column sums and squared norms:
+//   exchange 0:   c = W^T u0                       (partials over each workgroup's rows)
+//   use t:        v_t = normalize(c [* 1/|s_(t-1)|]);  s = W v_t (own rows);  publish W^T s and |s|^2 (own rows)
+//   exchange t+1: |s|^2 -> sigma_t = |s|, u_t = s / |s|;  W^T u_t = (W^T s) / |s| -> next use
+// (W^T of the UNnormalised s travels with |s|^2, so a use costs ONE exchange, not two.)  The exchange follows the
+// guide's small-payload recipe: every float is an 8-byte {epoch, value} granule stored and polled with relaxed
+// agent-scope atomics -- the data is its own flag, no fences, nothing depends on placement or dispatch order; epochs
+// count exchanges within the launch, the slots are double-buffered by exchange parity (a workgroup publishes exchange
+// x + 2 only after consuming every partial of x + 1, which exists only once every workgroup has consumed x) and are
+// zeroed by a memset node in front of every launch.  Sums over workgroups and waves run in index order: bitwise
+// reproducible, identical in every workgroup of a weight.  Spins are bounded (a timeout word is set and the launch
+// drains).  Training mode only (the power iteration); eval keeps the one-workgroup kernel.
+constexpr int SNS_THREADS = 256;
+constexpr int SNS_WAVES = SNS_THREADS / 64;
+constexpr int SNS_RW = 8;                       // rows per wave
+constexpr int SNS_ROWS = SNS_WAVES * SNS_RW;    // rows per workgroup
+constexpr int SNS_MAXCN = 64 * SN_CB;
+constexpr int SNS_MAXPARTS = 16;                // rows <= 512
+constexpr int SNS_XB = 8;                       // granule loads a thread keeps in flight
+struct SnSplitDesc {
+    const float *W;
+    float *u;
+    float *v;
+    long long R, Cn, uses, out_off, parts, x_off;      // x_off: granules into the exchange buffer
+};
+
+__device__ __forceinline__ float sns_block_sum(float v, float *scratch) {
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    v = wave_sum(v);
+    __syncthreads();
+    if (lane == 0) scratch[wave] = v;
+    __syncthreads();
+    float t = 0.0f;
+#pragma unroll
+    for (int w = 0; w < SNS_WAVES; ++w) t += scratch[w];
+    return t;
+}
+
+__global__ __launch_bounds__(SNS_THREADS) void spectral_norm_split_kernel(const SnSplitDesc *__restrict__ desc,
+                                                                          const int2 *__restrict__ part_map,
+                                                                          float *__restrict__ out,
+                                                                          unsigned long long *xws,
+                                                                          unsigned *tmo, float eps) {
+    __shared__ float sv[SNS_MAXCN], sc[SNS_MAXCN + 1], slab[SNS_WAVES * SNS_MAXCN], su[SNS_ROWS], ss[SNS_ROWS],
+        scratch[16], part[SNS_MAXPARTS * (SNS_MAXCN + 1)];
+    const int2 pm = part_map[blockIdx.x];
+    const SnSplitDesc d = desc[pm.x];
+    const int g = pm.y, G = (int)d.parts, R = (int)d.R, Cn = (int)d.Cn, uses = (int)d.uses;
+    if (G > SNS_MAXPARTS || Cn > SNS_MAXCN) {              // (uniform over a weight's workgroups: nobody waits)
+        if (threadIdx.x == 0) atomicOr(tmo, 2u);
+        return;
+    }
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int r0 = g * SNS_ROWS;
+    const int nrows = R - r0 < SNS_ROWS ? R - r0 : SNS_ROWS;
+    const size_t n = (size_t)R * Cn;
+    const int XS = Cn + 1;                              // granules per workgroup and exchange
+    unsigned long long *X = xws + d.x_off;
+
+    float w[SNS_RW][SN_CB];
+#pragma unroll
+    for (int r = 0; r < SNS_RW; ++r) {
+        const int lr = wave * SNS_RW + r;
+        const float *wr = d.W + (size_t)(r0 + (lr < nrows ? lr : 0)) * Cn;
+#pragma unroll
+        for (int c = 0; c < SN_CB; ++c) {
+            const int j = lane + 64 * c;
+            w[r][c] = (lr < nrows && j < Cn) ? wr[j] : 0.0f;
+        }
+    }
+    if (tid < SNS_ROWS) su[tid] = tid < nrows ? d.u[r0 + tid] : 0.0f;     // (v0 is not an input of the iteration)
+    __syncthreads();
+
+    // partial column sums over this workgroup's rows with coefficients coef[row] (LDS) + a scalar -> exchange x
+    auto publish = [&](int x, const float *coef, float scalar, bool columns) {
+        unsigned long long *slot = X + ((size_t)(x & 1) * G + g) * XS;
+        const unsigned long long tag = (unsigned long long)(x + 1) << 32;
+        if (columns) {
+            float acc[SN_CB];
+#pragma unroll
+            for (int c = 0; c < SN_CB; ++c) acc[c] = 0.0f;
+#pragma unroll
+            for (int r = 0; r < SNS_RW; ++r) {
+                const float cf = coef[wave * SNS_RW + r];
+#pragma unroll
+                for (int c = 0; c < SN_CB; ++c) acc[c] += w[r][c] * cf;
+            }
+#pragma unroll
+            for (int c = 0; c < SN_CB; ++c) {
+                const int j = lane + 64 * c;
+                if (j < Cn) slab[wave * SNS_MAXCN + j] = acc[c];
+            }
+            __syncthreads();
+            for (int j = tid; j < Cn; j += SNS_THREADS) {
+                float t = 0.0f;
+#pragma unroll
+                for (int ww = 0; ww < SNS_WAVES; ++ww) t += slab[ww * SNS_MAXCN + j];
+                __hip_atomic_store(slot + j, tag | (unsigned long long)__float_as_uint(t), __ATOMIC_RELAXED,
+                                   __HIP_MEMORY_SCOPE_AGENT);
+            }
+        }
+        if (tid == 0)
+            __hip_atomic_store(slot + Cn, tag | (unsigned long long)__float_as_uint(scalar), __ATOMIC_RELAXED,
+                               __HIP_MEMORY_SCOPE_AGENT);
+    };
+    // sc[0..Cn) (columns) and sc[Cn] (scalar) = the partials of exchange x summed over the workgroups in index order.
+    // The G * (Cn + 1) granules of an exchange are one contiguous array: the threads sweep it with SNS_XB independent
+    // loads in flight each (a dependent poll per granule cost ~28 us per exchange: 16-24 remote round trips in a row),
+    // re-poll what has not arrived, park the values in LDS and add them up per column afterwards.
+    auto poll = [&](const unsigned long long *p, unsigned long long q, unsigned want) {
+        for (unsigned spins = 0; (unsigned)(q >> 32) != want; ++spins) {
+            if (spins > (1u << 22)) {                               // bounded: flag it and drain
+                atomicOr(tmo, 1u);
+                break;
+            }
+            __builtin_amdgcn_s_sleep(1);
+            q = __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
+        return __uint_as_float((unsigned)q);
+    };
+    auto consume = [&](int x, bool columns) {
+        const unsigned long long *base = X + (size_t)(x & 1) * G * XS;
+        const unsigned want = (unsigned)(x + 1);
+        if (columns) {
+            const int total = G * XS;
+            for (int e0 = 0; e0 < total; e0 += SNS_THREADS * SNS_XB) {
+                unsigned long long q[SNS_XB];
+#pragma unroll
+                for (int k = 0; k < SNS_XB; ++k) q[k] = 0ull;                  // tag 0: not arrived
+                // every pass re-issues the loads of ALL granules still missing, together (one round trip per pass)
+                for (unsigned spins = 0;; ++spins) {
+                    bool missing = false;
+#pragma unroll
+                    for (int k = 0; k < SNS_XB; ++k) {
+                        const int e = e0 + k * SNS_THREADS + tid;
+                        if (e < total && (unsigned)(q[k] >> 32) != want)
+                            q[k] = __hip_atomic_load(base + e, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    }
+#pragma unroll
+                    for (int k = 0; k < SNS_XB; ++k) {
+                        const int e = e0 + k * SNS_THREADS + tid;
+                        missing |= e < total && (unsigned)(q[k] >> 32) != want;
+                    }
+                    if (!missing) break;
+                    if (spins > (1u << 20)) {                                  // bounded: flag it and drain
+                        atomicOr(tmo, 1u);
+                        break;
+                    }
+                    __builtin_amdgcn_s_sleep(1);
+                }
+#pragma unroll
+                for (int k = 0; k < SNS_XB; ++k) {
+                    const int e = e0 + k * SNS_THREADS + tid;
+                    if (e < total) part[e] = __uint_as_float((unsigned)q[k]);
+                }
+            }
+            __syncthreads();
+            for (int j = tid; j <= Cn; j += SNS_THREADS) {
+                float t = 0.0f;
+                for (int gg = 0; gg < G; ++gg) t += part[gg * XS + j];
+                sc[j] = t;
+            }
+        } else {
+            if (tid < G) {
+                const unsigned long long *p = base + (size_t)tid * XS + Cn;
+                part[tid] = poll(p, __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT), want);
+            }
+            __syncthreads();
+            if (tid == 0) {
+                float t = 0.0f;
+                for (int gg = 0; gg < G; ++gg) t += part[gg];
+                sc[Cn] = t;
+            }
+        }
+        __syncthreads();
+    };
+
+    // W / sigma of a finished use, from the registers.  Called AFTER the next exchange's partials are published: the 64 KB
+    // of stores then drain while the workgroup would wait for the other workgroups' granules anyway (in front of the
+    // publish they cost 6 of a use's 19 us: tools/tune_sn.py with -DTPG_SNS_NO_OUT).
+    auto write_scaled = [&](int use, float sg) {
+        float *o = out + d.out_off + (size_t)use * sn_stride(R, Cn);
+#pragma unroll
+        for (int r = 0; r < SNS_RW; ++r) {
+            const int lr = wave * SNS_RW + r;
+            if (lr < nrows) {
+                float *orow = o + (size_t)(r0 + lr) * Cn;
+#pragma unroll
+                for (int c = 0; c < SN_CB; ++c) {
+                    const int j = lane + 64 * c;
+                    if (j < Cn) orow[j] = w[r][c] / sg;
+                }
+            }
+        }
+    };
+    publish(0, su, 0.0f, true);
+    float sigma = 0.0f;
+    for (int t = 0; t <= uses; ++t) {
+        consume(t, t < uses);
+        float inv_s = 1.0f;
+        if (t > 0) {
+            // close use t - 1: sigma, u, and its outputs
+            const float nrm = sc[Cn];
+            inv_s = 1.0f / fmaxf(sqrtf(nrm), eps);
+            sigma = nrm * inv_s;
+            float *o = out + d.out_off + (size_t)(t - 1) * sn_stride(R, Cn);
+            float *ou = o + n, *ov = ou + R;
+            if (tid < SNS_ROWS) su[tid] = ss[tid] * inv_s;
+            __syncthreads();
+            if (tid < nrows) ou[r0 + tid] = su[tid];
+            if (g == 0) {
+                for (int j = tid; j < Cn; j += SNS_THREADS) ov[j] = sv[j];
+                if (tid == 0) ov[Cn] = sigma;
+            }
+        }
+        if (t == uses) {
+            write_scaled(t - 1, sigma);
+            break;
+        }
+        // v_t = normalize(W^T u_(t-1)),  W^T u_(t-1) = (sum of the partials) [* 1/|s|]
+        float nv = 0.0f;
+        for (int j = tid; j < Cn; j += SNS_THREADS) {
+            const float x = t > 0 ? sc[j] * inv_s : sc[j];
+            sc[j] = x;
+            nv += x * x;
+        }
+        nv = sns_block_sum(nv, scratch);
+        const float inv_v = 1.0f / fmaxf(sqrtf(nv), eps);
+        for (int j = tid; j < Cn; j += SNS_THREADS) sv[j] = sc[j] * inv_v;
+        __syncthreads();
+        // s = W v_t on this workgroup's rows
+        float vloc[SN_CB];
+#pragma unroll
+        for (int c = 0; c < SN_CB; ++c) {
+            const int j = lane + 64 * c;
+            vloc[c] = j < Cn ? sv[j] : 0.0f;
+        }
+#pragma unroll
+        for (int r = 0; r < SNS_RW; ++r) {
+            float a = 0.0f;
+#pragma unroll
+            for (int c = 0; c < SN_CB; ++c) a += w[r][c] * vloc[c];
+            a = wave_sum(a);
+            if (lane == 0) ss[wave * SNS_RW + r] = a;
+        }
+        __syncthreads();
+        float ns = 0.0f;
+        if (tid == 0) {
+            for (int i = 0; i < nrows; ++i) ns += ss[i] * ss[i];
+        }
+        publish(t + 1, ss, ns, t + 1 < uses);
+        if (t > 0) write_scaled(t - 1, sigma);
+    }
+    // the buffers after the last use
+    if (tid < nrows) d.u[r0 + tid] = su[tid];
+    if (g == 0)
+        for (int j = tid; j < Cn; j += SNS_THREADS) d.v[j] = sv[j];
+}
+
 // backward: gradients of all uses are packed in one flat buffer (use t of weight m at
 // g + g_off + t*R*Cn), dW[m] (at dw + dw_off) = sum over uses; descriptors hold only sizes
 // and offsets, so they are built once and stay valid for every later call (and for replay
@@ -294,6 +558,28 @@ extern "C" int tpg_spectral_norm_multi_fwd(const void *desc, int M, int max_rc, 
     TPG_RETURN_IF_LAUNCH_FAILED();
     return TPG_OK;
 }
+
+extern "C" int tpg_spectral_norm_multi_fwd_split(const void *desc, const void *part_map, int total_parts, int max_cn,
+                                                 float *out, void *xws, long long xws_words, float eps, void *stream) {
+    if (total_parts < 0 || xws_words < 2 || !desc || !part_map || !out || !xws) return TPG_ERR_ARG;
+    if (total_parts == 0) return TPG_OK;
+    if (max_cn > SNS_MAXCN) return TPG_ERR_UNSUPPORTED;
+    if (reinterpret_cast<uintptr_t>(xws) & 15) return TPG_ERR_UNSUPPORTED;
+    hipStream_t st = tpg_stream(stream);
+    // every polled word back to epoch 0 (a memset node in a captured step); xws_words 8-byte words, the last one holds
+    // the timeout flag
+    if (hipMemsetAsync(xws, 0, sizeof(unsigned long long) * (size_t)xws_words, st) != hipSuccess) return TPG_ERR_LAUNCH;
+    unsigned long long *x = static_cast<unsigned long long *>(xws);
+    hipLaunchKernelGGL(spectral_norm_split_kernel, dim3(total_parts), dim3(SNS_THREADS), 0, st,
+                       static_cast<const SnSplitDesc *>(desc), static_cast<const int2 *>(part_map), out, x,
+                       reinterpret_cast<unsigned *>(x + xws_words - 1), eps);
+    TPG_RETURN_IF_LAUNCH_FAILED();
+    return TPG_OK;
+}
+
+extern "C" int tpg_spectral_norm_split_rows(void) { return SNS_ROWS; }
+extern "C" int tpg_spectral_norm_split_max_cn(void) { return SNS_MAXCN; }
+extern "C" int tpg_spectral_norm_split_max_rows(void) { return SNS_ROWS * SNS_MAXPARTS; }
 
 extern "C" long long tpg_spectral_norm_multi_bwd_scratch(int M, int max_uses) {
     return (long long)M * max_uses * SNB_CH;          // floats

@@ -151,7 +151,9 @@ class GraphedFluidStep:
         # clouds at the start of the step, fake ones as soon as the generator's forward is done)
         self.sides = [torch.cuda.Stream(dev) for _ in range(2)]
         self.branch = torch.cuda.Stream(dev)       # the discriminators' updates
-        self.branch2 = torch.cuda.Stream(dev)
+        # the temporal update is the branch that finishes last (tools/ab_env.py TPGAN_WHATIF_SKIP=t: 12.9 -> 10.0 ms
+        # without it, 11.4 without the spatial one): TPGAN_BRANCH2_PRIO=-1 gives its stream the higher priority (A/B)
+        self.branch2 = torch.cuda.Stream(dev, priority=int(os.environ.get("TPGAN_BRANCH2_PRIO", "0")))
         # round 3: two more parallel branches INSIDE the generator step -- the generator's mask head beside its
         # upsampling head (srnet.SRNet.body), and the spatial discriminator's forward (hence backward) of the generator
         # step beside the temporal one's.  TPGAN_GSTEP_BRANCHES=0: the serial form (A/B timing).
@@ -377,26 +379,24 @@ class GraphedFluidStep:
             # issue order = the eager step's (and the reference's, train_step_final.py:171-214): the
             # temporal update first.  The streams decide what runs where; the ISSUE order decides
             # which Philox offsets the heads' dropout draws get inside a captured graph.
-            with torch.cuda.stream(self.branch2):
-                for t in k["fakes"] + k["trues"] + [lab] + _plan_tensors(k["plan_t"]):
-                    t.record_stream(self.branch2)
-                with _autocast(self.amp, self.dev):
-                    fake, true = self.Dt.forward_passes([k["fakes"], k["trues"]], self.opt.R, plan=k["plan_t"])
-                loss_t = (0.5 * ((true.float() - lab[0]) ** 2 + (fake.float() - lab[1]) ** 2)).mean()
-                self.ot.zero_grad(set_to_none=True)
-                loss_t.backward()
-                k["tempo_dis_loss"] = loss_t.detach()
-                k["tempo_dis_loss"].record_stream(main)
-            with torch.cuda.stream(self.branch):
-                for t in [k["fake_s"], k["true_s"], lab] + _plan_tensors(k["plan_s"]):
-                    t.record_stream(self.branch)
-                with _autocast(self.amp, self.dev):
-                    fake, true = self.Ds.forward_passes([k["fake_s"], k["true_s"]], plan=k["plan_s"])
-                loss_s = (0.5 * ((true.float() - lab[0]) ** 2 + (fake.float() - lab[1]) ** 2)).mean()
-                self.os.zero_grad(set_to_none=True)
-                loss_s.backward()
-                k["spatial_dis_loss"] = loss_s.detach()
-                k["spatial_dis_loss"].record_stream(main)
+            def update(dis, optim, branch, passes, plan, key, **kw):
+                with torch.cuda.stream(branch):
+                    for t in [x for p in passes for x in (p if isinstance(p, list) else [p])] + [lab] + _plan_tensors(plan):
+                        t.record_stream(branch)
+                    with _autocast(self.amp, self.dev):
+                        fake, true = dis.forward_passes(passes, *kw.get("args", ()), plan=plan)
+                    loss = (0.5 * ((true.float() - lab[0]) ** 2 + (fake.float() - lab[1]) ** 2)).mean()
+                    optim.zero_grad(set_to_none=True)
+                    loss.backward()
+                    k[key] = loss.detach()
+                    k[key].record_stream(main)
+            skip = os.environ.get("TPGAN_WHATIF_SKIP", "")        # timing aid (tools/ab_env.py): leave an update out
+            if skip:
+                k["tempo_dis_loss"] = k["spatial_dis_loss"] = torch.zeros((), device=self.dev)
+            if "t" not in skip:
+                update(self.Dt, self.ot, self.branch2, [k["fakes"], k["trues"]], k["plan_t"], "tempo_dis_loss", args=(self.opt.R,))
+            if "s" not in skip:
+                update(self.Ds, self.os, self.branch, [k["fake_s"], k["true_s"]], k["plan_s"], "spatial_dis_loss")
         else:
             k["tempo_dis_loss"] = torch.zeros((), device=self.dev)
             k["spatial_dis_loss"] = torch.zeros((), device=self.dev)

@@ -684,7 +684,25 @@ class HipBackend:
                 out_total += st * n
                 g_total += R * Cn * n
                 dw_total += R * Cn
-            plan = dict(fwd=torch.tensor(fwd, dtype=torch.int64).to(dev), bwd=torch.tensor(bwd, dtype=torch.int64).to(dev),
+            # split form (training mode, csrc/spectral.hip): rows of a weight over several workgroups, one exchange per use
+            rows, split = self.lib.tpg_spectral_norm_split_rows(), None
+            if (SN_SPLIT[0] and max(W.shape[1] for W in Ws) <= self.lib.tpg_spectral_norm_split_max_cn()
+                    and max(W.shape[0] for W in Ws) <= self.lib.tpg_spectral_norm_split_max_rows()):
+                sd, pmap, words, off = [], [], 0, 0
+                for m, (W, u, v, n) in enumerate(zip(Ws, us, vs, uses)):
+                    R, Cn = W.shape
+                    parts = (R + rows - 1) // rows
+                    sd += [W.data_ptr(), u.data_ptr(), v.data_ptr(), R, Cn, n, off, parts, words]
+                    pmap += [(m, g) for g in range(parts)]
+                    words += 2 * parts * (Cn + 1)
+                    off += sn_multi_stride(R, Cn) * n
+                words = (words + 1 + 1) & ~1                      # + the timeout word, whole 16-byte units
+                split = dict(desc=torch.tensor(sd, dtype=torch.int64).to(dev),
+                             pmap=torch.tensor(pmap, dtype=torch.int32).to(dev).contiguous(), parts=len(pmap),
+                             xws=torch.zeros(words, dtype=torch.int64, device=dev), words=words,
+                             max_cn=max(W.shape[1] for W in Ws))
+            plan = dict(split=split,
+                        fwd=torch.tensor(fwd, dtype=torch.int64).to(dev), bwd=torch.tensor(bwd, dtype=torch.int64).to(dev),
                         layout=layout, goffs=goffs, dwoffs=dwoffs, out_total=out_total, g_total=g_total,
                         dw_total=dw_total, max_rc=max(W.shape[0] + W.shape[1] for W in Ws), M=len(Ws),
                         max_uses=max(int(n) for n in uses))
@@ -734,6 +752,12 @@ class HipBackend:
         plan = self._sn_plan(Ws, us, vs, uses)
         out = torch.empty(plan["out_total"], dtype=torch.float32, device=Ws[0].device)
         nbytes = 4 * sum((1 + n) * W.numel() for W, n in zip(Ws, uses))
+        sp = plan["split"]
+        if iterate and sp is not None:
+            self._call("tpg_spectral_norm_multi_fwd_split", "spectral_norm_fwd", nbytes, out,
+                       _ptr(sp["desc"]), _ptr(sp["pmap"]), sp["parts"], sp["max_cn"], _ptr(out), _ptr(sp["xws"]),
+                       sp["words"], float(eps))
+            return out, plan
         self._call("tpg_spectral_norm_multi_fwd", "spectral_norm_fwd", nbytes, out,
                    _ptr(plan["fwd"]), plan["M"], plan["max_rc"], _ptr(out), int(iterate), float(eps))
         return out, plan
@@ -746,6 +770,11 @@ class HipBackend:
         self._call("tpg_spectral_norm_multi_bwd", "spectral_norm_bwd", 4 * (3 * plan["g_total"] + plan["dw_total"]),
                    out, _ptr(plan["bwd"]), plan["M"], maxu, _ptr(gflat), _ptr(out), _ptr(dw), _ptr(scratch))
         return dw
+
+
+# spectral norm of a forward's weights with every weight's rows split over several workgroups (TPGAN_SN_SPLIT=0: the
+# one-workgroup-per-weight kernel, for A/B runs)
+SN_SPLIT = [os.environ.get("TPGAN_SN_SPLIT", "1") != "0"]
 
 
 def sn_multi_stride(R, Cn):

@@ -111,6 +111,12 @@ def test_new_entries_reject_bad_arguments_before_any_launch(hip_lib):
     assert hip_lib.tpg_rowcombine_edge_bwd(p, p, p, p, None, 0, 0, 1, 8, 4, 8, 0.2, 0.2, p, None) == -1
     assert hip_lib.tpg_rowcombine_edge_bwd(p, p, p, p, p, 0, 0, 1, 8, 4, 8, 0.2, 0.2, None, None) == -1
     assert hip_lib.tpg_rowcombine_edge_bwd(p, p, p, p, p, 0, 0, 1, 8, 4, 6, 0.2, 0.2, p, None) == -3
+    # split spectral norm: descriptor, part map and a 16-byte aligned exchange buffer required; <= 576 columns
+    assert hip_lib.tpg_spectral_norm_multi_fwd_split(None, p, 1, 64, p, p, 8, 1e-12, None) == -1
+    assert hip_lib.tpg_spectral_norm_multi_fwd_split(p, p, 1, 64, p, None, 8, 1e-12, None) == -1
+    assert hip_lib.tpg_spectral_norm_multi_fwd_split(p, p, 0, 64, p, p, 8, 1e-12, None) == 0
+    assert hip_lib.tpg_spectral_norm_multi_fwd_split(p, p, 1, 577, p, p, 8, 1e-12, None) == -3
+    assert hip_lib.tpg_spectral_norm_split_rows() == 32 and hip_lib.tpg_spectral_norm_split_max_cn() == 576
     # statistics / backward sums with the folded constants from the same finalize launch
     assert hip_lib.tpg_rowbn_stats_consts(p, 1, 64, 64, 1e-5, 0.1, None, None, None, None, p, p, p, p, None, p, 1, None) == -1
     assert hip_lib.tpg_rowbn_stats_consts(p, 1, 64, 60, 1e-5, 0.1, None, None, None, None, p, p, p, p, p, p, 1, None) == -3

@@ -689,6 +689,46 @@ def test_spectral_norm_multi_matches_chained_single_calls(hip):
         assert torch.allclose(dw[off:off + R_ * Cn].view(R_, Cn), ref, rtol=1e-4, atol=1e-5)
 
 
+def test_spectral_norm_split_equals_the_one_workgroup_kernel(hip):
+    """The split form (rows of a weight over several workgroups, granule exchange, csrc/spectral.hip) against the
+    one-workgroup kernel on the discriminators' weight shapes with up to 16 chained uses: every use's W / sigma, u, v,
+    sigma and the final buffers to summation order; a second launch from the same state is bit-identical; no spin timed
+    out."""
+    from tpgan_amd import ops
+    rng = np.random.default_rng(11)
+    shapes = [(1, 64), (64, 6), (64, 256), (128, 131), (256, 259), (256, 515), (256, 515), (512, 256), (256, 512), (40, 70)]
+    uses = [1, 3, 6, 2, 6, 16, 5, 6, 1, 4]
+    Ws = [dev(rng.standard_normal(s).astype(np.float32) * 0.1) for s in shapes]
+    u0 = [torch.nn.functional.normalize(torch.randn(s[0], device="cuda"), dim=0) for s in shapes]
+    v0 = [torch.nn.functional.normalize(torch.randn(s[1], device="cuda"), dim=0) for s in shapes]
+    runs = {}
+    for name, split in (("split", True), ("split2", True), ("one", False)):
+        ops.SN_SPLIT[0] = split
+        hip._sn_plans.clear()
+        us, vs = [u.clone() for u in u0], [v.clone() for v in v0]
+        flat, plan = hip.spectral_norm_multi_fwd(Ws, us, vs, uses, True, 1e-12)
+        torch.cuda.synchronize()
+        if split:
+            assert plan["split"] is not None and plan["split"]["parts"] > len(shapes)
+            assert int(plan["split"]["xws"][-1]) == 0, "a bounded spin of the exchange timed out"
+        runs[name] = (flat.clone(), us, vs, plan)
+    ops.SN_SPLIT[0] = True
+    hip._sn_plans.clear()
+    a, b = runs["split"], runs["one"]
+    for x, y in zip(a[1] + a[2], runs["split2"][1] + runs["split2"][2]):
+        assert torch.equal(x, y)
+    for (R_, Cn), n, (off, st) in zip(shapes, uses, a[3]["layout"]):
+        for t in range(n):
+            ga, gb = a[0][off + t * st: off + (t + 1) * st], b[0][off + t * st: off + (t + 1) * st]
+            used = R_ * Cn + R_ + Cn + 1                      # (the record is padded to whole 16-byte units)
+            assert torch.equal(ga[:used], runs["split2"][0][off + t * st: off + t * st + used]), (R_, Cn, t)
+            assert torch.allclose(ga[:R_ * Cn + R_ + Cn], gb[:R_ * Cn + R_ + Cn], rtol=2e-5, atol=2e-6), (R_, Cn, t)
+            sa, sb = float(ga[R_ * Cn + R_ + Cn]), float(gb[R_ * Cn + R_ + Cn])
+            assert abs(sa - sb) <= 1e-5 * abs(sb), (R_, Cn, t)
+    for x, y in zip(a[1] + a[2], b[1] + b[2]):
+        assert torch.allclose(x, y, atol=2e-6)
+
+
 # ------------------------------------------------------------------ fused cubic interpolation
 @pytest.mark.parametrize("B,Nq,Np,F,cutoff", [(2, 500, 700, 3, 0.12), (3, 1024, 4096, 3, 0.16), (1, 64, 40, 5, 0.5)])
 def test_cubic_interp_matches_oracle(hip, B, Nq, Np, F, cutoff):

@@ -101,7 +101,11 @@ def _compare_modules(ma, mb, outs_a, outs_b, rtol_out=2e-3, grad_rel=1e-2):
             float((oa - ob).abs().max())
     sd_a, sd_b = ma.state_dict(), mb.state_dict()
     for k in sd_a:                          # running statistics, spectral-norm vectors, counters
-        assert torch.allclose(sd_a[k].float(), sd_b[k].float(), rtol=1e-4, atol=1e-5), k
+        # (the head's BatchNorm1d statistics sit behind every flow embedding and a batch of 4: the split spectral-norm
+        # kernel evaluates W^T u as (W^T s) / |s| inside a chain of uses and from the stored u at the start of a call --
+        # 1e-7 apart -- which reaches them as ~1e-5 at T = 8; logits are held at 2e-3 above)
+        atol = 5e-5 if k.startswith("fc_layers") else 1e-5
+        assert torch.allclose(sd_a[k].float(), sd_b[k].float(), rtol=1e-4, atol=atol), (k, float((sd_a[k].float() - sd_b[k].float()).abs().max()))
     ga = torch.cat([p.grad.reshape(-1) for (n, p), (_, q) in zip(ma.named_parameters(), mb.named_parameters())
                     if p.grad is not None and q.grad is not None])
     gb = torch.cat([q.grad.reshape(-1) for (n, p), (_, q) in zip(ma.named_parameters(), mb.named_parameters())
@@ -138,8 +142,23 @@ def test_tempo_discriminator_forward_passes_equals_two_forwards():
         assert float((x.grad - y.grad).norm() / (y.grad.norm() + 1e-12)) <= 3e-2
 
 
+@pytest.fixture(params=[False, True], ids=["sn_one_workgroup", "sn_split"])
+def sn_split(request):
+    """Both spectral-norm kernels.  The one-workgroup kernel evaluates a chain of uses exactly as successive calls do,
+    so it isolates the SEGMENT logic under test; the split kernel (the default, csrc/spectral.hip) evaluates W^T u as
+    (W^T s) / |s| inside a chain and from the stored u at the start of a call -- 1e-7 apart."""
+    from tpgan_amd import ops
+    be = ops.backend_for(torch.zeros(1, device="cuda"))
+    prev = ops.SN_SPLIT[0]
+    ops.SN_SPLIT[0] = request.param
+    be._sn_plans.clear()
+    yield request.param
+    ops.SN_SPLIT[0] = prev
+    be._sn_plans.clear()
+
+
 @pytest.mark.parametrize("kind,T,N", [("fluid", 5, 2048), ("action", 8, 1024), ("fluid", 5, 16384)])
-def test_long_clip_tempo_discriminators_forward_passes_equal_two_forwards(kind, T, N):
+def test_long_clip_tempo_discriminators_forward_passes_equal_two_forwards(kind, T, N, sn_split):
     """The same equivalence at the clip lengths of cfg5 (FluidTempoDis(5): 10 flow embeddings, the depth-d conv used
     4 / 3 / 2 / 1 times per pass) and cfg4 (ActionTempoDis(8): 28) -- VERDICT r2 item 1(i): GPUTEST_r02's only
     diverging term was the temporal discriminator's update at T = 5.  Batch 4 (with 2 clips the head's BatchNorm1d is a
@@ -171,7 +190,9 @@ def test_long_clip_tempo_discriminators_forward_passes_equal_two_forwards(kind, 
     # relative L2 difference measured 1.6e-2 (library GEMMs) / 3.9e-2 (hand-written row-linear kernels) at T = 8 --
     # the same two evaluations, another rounding pattern: the figure is a property of the max-pool routing, the bound
     # (6e-2) is there for what it can catch: a segment run with the wrong weights or statistics is off by O(1).
-    _compare_modules(Da, Db, outs_a, outs_b, grad_rel=6e-2)
+    # With the split spectral-norm kernel the two evaluations also differ by 1e-7 in every weight: 7.2e-2 measured at
+    # T = 8 -- the routing noise again, so that case gets 0.12 and the segment logic is held to 6e-2 by the other kernel.
+    _compare_modules(Da, Db, outs_a, outs_b, grad_rel=0.12 if sn_split else 6e-2)
     for x, y in zip(fa, fb):
         assert float((x.grad - y.grad).norm() / (y.grad.norm() + 1e-12)) <= 6e-2
 
