@@ -199,6 +199,20 @@ int tpg_rowcombine_edge_bwd(const void *gout, const int32_t *idx, const int32_t 
                             const void *Y, int dtype_in, int dtype_out, int B, int N, int K, int C, float slope_a,
                             float slope_e, void *gY, void *stream);
 
+/* ---- BatchNorm1d + LeakyReLU + dropout mask of a classification head (discriminator.py:503-516,598-612) ----------
+ * h (B,C) fp32 rows of a head's hidden layer, TRAINING mode: batch statistics over the B rows (biased variance, eps),
+ *   z = (h - mean) * rstd * gamma + beta;  y = (z > 0 ? z : slope * z) * mask
+ * mask (B,C, may be NULL) = the dropout's scaled keep mask (0 or 1 / (1 - p)), drawn by the caller; running statistics
+ * (may be NULL) are updated with `momentum` and the unbiased variance, *num_batches_tracked (may be NULL) is incremented;
+ * mean / rstd (C) are outputs, kept for the backward.  B == 1 is an argument error, as in nn.BatchNorm1d.
+ * Backward: dh (B,C), dgamma / dbeta (C, may be NULL); the activation's sign is recomputed from h. */
+int tpg_head_bn_act_fwd(const float *h, int B, int C, const float *gamma, const float *beta, float *running_mean,
+                        float *running_var, long long *num_batches_tracked, float momentum, float eps, float slope,
+                        const float *mask, float *y, float *mean, float *rstd, void *stream);
+int tpg_head_bn_act_bwd(const float *gy, const float *h, const float *mean, const float *rstd, const float *gamma,
+                        const float *beta, float slope, const float *mask, int B, int C, float *dh, float *dgamma,
+                        float *dbeta, void *stream);
+
 /* ---- fused BatchNorm + LeakyReLU (+ max over K neighbours) on channels-last rows ----------
  * The [conv -> BatchNorm2d -> (Leaky)ReLU]* -> max-over-nsample tail of every shared MLP
  * (discriminator.py:63-78,145-150,279-282) on rows x (P,C), P = B*S*ns:

@@ -232,6 +232,39 @@ def rowcombine_edge_bwd(gout, idx, Y, slope_a=0.2, slope_e=0.2):
     return np.concatenate([gE, gA], axis=2)
 
 
+# ---- a head's BatchNorm1d + LeakyReLU + dropout mask (include/tpgan_ops.h, tpg_head_bn_act_*): numpy restatement
+# (float64 inside) of nn.BatchNorm1d in training mode -> nn.LeakyReLU -> x * mask, reference discriminator.py:503-516.
+def head_bn_act_fwd(h, gamma, beta, running_mean, running_var, momentum, eps, slope, mask):
+    h64 = np.asarray(h, np.float64)
+    B = h64.shape[0]
+    mean = h64.mean(0)
+    var = h64.var(0)
+    rstd = 1.0 / np.sqrt(var + eps)
+    z = (h64 - mean) * rstd * (1.0 if gamma is None else np.asarray(gamma, np.float64)) + \
+        (0.0 if beta is None else np.asarray(beta, np.float64))
+    y = np.where(z > 0, z, z * slope)
+    if mask is not None:
+        y = y * np.asarray(mask, np.float64)
+    new_rm = None if running_mean is None else (1 - momentum) * np.asarray(running_mean, np.float64) + momentum * mean
+    new_rv = None if running_var is None else \
+        (1 - momentum) * np.asarray(running_var, np.float64) + momentum * var * B / (B - 1)
+    f = lambda a: None if a is None else a.astype(np.float32)
+    return f(y), f(mean), f(rstd), f(new_rm), f(new_rv)
+
+
+def head_bn_act_bwd(gy, h, mean, rstd, gamma, beta, slope, mask):
+    h64, g64 = np.asarray(h, np.float64), np.asarray(gy, np.float64)
+    B = h64.shape[0]
+    ga = 1.0 if gamma is None else np.asarray(gamma, np.float64)
+    be = 0.0 if beta is None else np.asarray(beta, np.float64)
+    xh = (h64 - np.asarray(mean, np.float64)) * np.asarray(rstd, np.float64)
+    gz = g64 if mask is None else g64 * np.asarray(mask, np.float64)
+    gz = np.where(xh * ga + be > 0, gz, gz * slope)
+    db, dg = gz.sum(0), (gz * xh).sum(0)
+    dh = ga * np.asarray(rstd, np.float64) * (gz - db / B - xh * dg / B)
+    return dh.astype(np.float32), dg.astype(np.float32), db.astype(np.float32)
+
+
 # ---- fused BatchNorm + LeakyReLU (+ max over K) on rows: numpy restatement (float64 inside) of the
 # build's own fused form of [BatchNorm2d -> (Leaky)ReLU -> max over nsample]
 # (reference discriminator.py:63-78,145-150,279-282); equality with the reference is pinned at

@@ -92,6 +92,24 @@ class OracleBackend:
     def rowcombine_edge_bwd(self, gout, idx, Y, slope_a, slope_e, inverse=None):
         return _t(R.rowcombine_edge_bwd(_np(gout.float()), _np(idx), _np(Y.float()), slope_a, slope_e)).to(Y.dtype)
 
+    def head_bn_act_fwd(self, h, gamma, beta, running_mean, running_var, nbt, momentum, eps, slope, mask):
+        o = lambda t: None if t is None else _np(t.detach().float())
+        y, mean, rstd, rm, rv = R.head_bn_act_fwd(o(h), o(gamma), o(beta), o(running_mean), o(running_var), momentum, eps,
+                                                  slope, o(mask))
+        with torch.no_grad():
+            if running_mean is not None:
+                running_mean.copy_(_t(rm))
+            if running_var is not None:
+                running_var.copy_(_t(rv))
+            if nbt is not None:
+                nbt += 1
+        return _t(y), _t(mean), _t(rstd)
+
+    def head_bn_act_bwd(self, gy, h, mean, rstd, gamma, beta, slope, mask, need_affine):
+        o = lambda t: None if t is None else _np(t.detach().float())
+        dh, dg, db = R.head_bn_act_bwd(o(gy), o(h), o(mean), o(rstd), o(gamma), o(beta), slope, o(mask))
+        return _t(dh), (_t(dg) if need_affine else None), (_t(db) if need_affine else None)
+
     def cubic_interp(self, query, pos, field, cutoff):
         plain, pad, hits = R.cubic_interp(_np(query), _np(pos), _np(field), cutoff)
         return _t(plain), _t(pad), _t(hits)

@@ -41,6 +41,8 @@ SIGNATURES = {
     "tpg_rowcombine_bwd": [_P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _I, _I, _F, _P, _P, _P],
     "tpg_rowcombine_edge_fwd": [_P, _P, _I, _I, _I, _I, _I, _I, _F, _F, _P, _P],
     "tpg_rowcombine_edge_bwd": [_P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _F, _F, _P, _P],
+    "tpg_head_bn_act_fwd": [_P, _I, _I, _P, _P, _P, _P, _P, _F, _F, _F, _P, _P, _P, _P, _P],
+    "tpg_head_bn_act_bwd": [_P, _P, _P, _P, _P, _P, _F, _P, _I, _I, _P, _P, _P, _P],
     "tpg_rowbn_fwd": [_P, _I, _L, _I, _I, _F, _F, _I, _P, _P, _P, _P, _P, _P, _F, _P, _P, _P, _I, _P, _P, _I, _I, _P],
     "tpg_rowbn_bwd": [_P, _I, _P, _I, _P, _P, _I, _L, _I, _I, _I, _P, _P, _P, _P, _F, _P, _P, _P, _P, _I, _I, _P],
     "tpg_cubic_interp_f32": [_P, _P, _P, _I, _I, _I, _I, _F, _P, _P, _P, _P],

@@ -390,6 +390,27 @@ class HipBackend:
                    B, N, K, Cc, float(slope_a), float(slope_e), _ptr(gY))
         return gY
 
+    # ---- BatchNorm1d + LeakyReLU + dropout mask of a classification head (csrc/head.hip) ----
+    def head_bn_act_fwd(self, h, gamma, beta, running_mean, running_var, nbt, momentum, eps, slope, mask):
+        B, Cc = h.shape
+        y = torch.empty_like(h)
+        mean = torch.empty(Cc, dtype=torch.float32, device=h.device)
+        rstd = torch.empty(Cc, dtype=torch.float32, device=h.device)
+        self._call("tpg_head_bn_act_fwd", "head_bn_act", 4 * B * Cc * (3 if mask is not None else 2), h,
+                   _ptr(h), B, Cc, _ptr(gamma), _ptr(beta), _ptr(running_mean), _ptr(running_var), _ptr(nbt),
+                   float(momentum), float(eps), float(slope), _ptr(mask), _ptr(y), _ptr(mean), _ptr(rstd))
+        return y, mean, rstd
+
+    def head_bn_act_bwd(self, gy, h, mean, rstd, gamma, beta, slope, mask, need_affine):
+        B, Cc = h.shape
+        dh = torch.empty_like(h)
+        dg = torch.empty(Cc, dtype=torch.float32, device=h.device) if need_affine else None
+        db = torch.empty(Cc, dtype=torch.float32, device=h.device) if need_affine else None
+        self._call("tpg_head_bn_act_bwd", "head_bn_act_bwd", 4 * B * Cc * (4 if mask is not None else 3), h,
+                   _ptr(gy), _ptr(h), _ptr(mean), _ptr(rstd), _ptr(gamma), _ptr(beta), float(slope), _ptr(mask), B, Cc,
+                   _ptr(dh), _ptr(dg), _ptr(db))
+        return dh, dg, db
+
     # ---- fused BatchNorm + LeakyReLU (+ max over K) on rows (csrc/rowbn.hip) -------------
     def _bn_ws(self, x, C_, nseg=1):
         # one scratch buffer per (device, stream), reused by every call: launches on a stream are
@@ -1194,6 +1215,38 @@ def attach_inverse(idx, N):
         offs, lst = be.invert_index(idx, int(N))
         idx._tpg_inverse = (int(N), offs, lst)
     return idx
+
+
+# ------------------------------------------------ head: BatchNorm1d + LeakyReLU + dropout mask
+class _HeadBNAct(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, h, gamma, beta, running_mean, running_var, nbt, momentum, eps, slope, mask):
+        be = backend_for(h)
+        y, mean, rstd = be.head_bn_act_fwd(h, gamma, beta, running_mean, running_var, nbt, momentum, eps, slope, mask)
+        ctx.save_for_backward(h, mean, rstd, gamma, beta, mask)
+        ctx.slope = slope
+        return y
+
+    @staticmethod
+    def backward(ctx, gy):
+        h, mean, rstd, gamma, beta, mask = ctx.saved_tensors
+        need_affine = (gamma is not None and ctx.needs_input_grad[1]) or (beta is not None and ctx.needs_input_grad[2])
+        dh, dg, db = backend_for(gy).head_bn_act_bwd(gy.contiguous().float(), h, mean, rstd, gamma, beta, ctx.slope, mask,
+                                                     need_affine)
+        return (dh, dg if gamma is not None else None, db if beta is not None else None, None, None, None, None, None,
+                None, None)
+
+
+def head_bn_act(h, bn, slope, mask=None):
+    """Training-mode nn.BatchNorm1d `bn` (running statistics and batch counter updated like the module does) + LeakyReLU
+    (slope) + the product with a dropout's scaled keep mask, on the (B,C) fp32 rows of a head: one launch each way
+    (include/tpgan_ops.h, tpg_head_bn_act_*)."""
+    _need(h.dim() == 2 and h.dtype == torch.float32, "h must be (B,C) fp32")
+    _need(bn.momentum is not None and bn.track_running_stats, "needs a BatchNorm1d with a fixed momentum and running statistics")
+    _need(h.shape[0] > 1, "Expected more than 1 value per channel when training")
+    return _HeadBNAct.apply(h.contiguous(), bn.weight, bn.bias, bn.running_mean, bn.running_var, bn.num_batches_tracked,
+                            float(bn.momentum), float(bn.eps), float(slope),
+                            None if mask is None else mask.contiguous().float())
 
 
 # ------------------------------------------------ fused BatchNorm + LeakyReLU (+ max over K)

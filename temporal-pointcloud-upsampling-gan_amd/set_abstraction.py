@@ -20,6 +20,7 @@ weight, same single power iteration per call) is applied to the N un-grouped row
 BatchNorm over the (B*S*ns) row axis -- the same statistics as BatchNorm2d over (B,S,ns).
 """
 import contextlib
+import os
 from typing import List
 
 import numpy as np
@@ -732,6 +733,19 @@ def _head(dims, drops):
     return nn.Sequential(*layers)
 
 
+FUSED_HEAD = [os.environ.get("TPGAN_FUSED_HEAD", "1") != "0"]     # off: PyTorch's BatchNorm1d / LeakyReLU / Dropout (A/B runs)
+_ONES = {}
+
+
+def _ones_like(x):
+    """A constant tensor of ones of x's shape (kept: a fill launch per use otherwise; never written)."""
+    key = (tuple(x.shape), x.device, x.dtype)
+    t = _ONES.get(key)
+    if t is None:
+        t = _ONES[key] = torch.ones_like(x)
+    return t
+
+
 def _head_fp32(fc_layers, x):
     """The (B,C) classification head, always in fp32 (B rows: nothing to gain from bf16);
     spectrally-normalised linears use the fused kernel, everything else its own module."""
@@ -739,8 +753,27 @@ def _head_fp32(fc_layers, x):
         x = x.float()
         if not rows_first() or not isinstance(fc_layers, nn.Sequential):
             return fc_layers(x)                       # reference order: PyTorch's own hooks
-        for m in fc_layers:
-            x = rows_matmul(x, sn_weight(m), m.bias) if isinstance(m, nn.Linear) else m(x)
+        mods, i = list(fc_layers), 0
+        while i < len(mods):
+            m = mods[i]
+            if isinstance(m, nn.Linear):
+                x = rows_matmul(x, sn_weight(m), m.bias)
+            elif (FUSED_HEAD[0] and isinstance(m, nn.BatchNorm1d) and m.training and m.momentum is not None
+                  and m.track_running_stats and x.dim() == 2 and x.shape[0] > 1 and i + 1 < len(mods)
+                  and isinstance(mods[i + 1], nn.LeakyReLU)):
+                # BatchNorm1d -> LeakyReLU [-> Dropout] in ONE launch each way (ops.head_bn_act, csrc/head.hip); the
+                # dropout's scaled keep mask is drawn by the module itself on a constant tensor of ones -- the same
+                # draws, in the same order, as its call on the activations
+                act, drop, mask = mods[i + 1], None, None
+                if i + 2 < len(mods) and isinstance(mods[i + 2], nn.Dropout):
+                    drop = mods[i + 2]
+                    if drop.training and drop.p > 0.0:
+                        mask = drop(_ones_like(x))
+                x = ops.head_bn_act(x, m, act.negative_slope, mask)
+                i += 1 if drop is None else 2
+            else:
+                x = m(x)
+            i += 1
         return x
 
 

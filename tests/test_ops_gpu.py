@@ -2,6 +2,8 @@
 oracle on the same seeded inputs.  Neighbour / sample indices must be BIT-EXACT, distances
 produced by the canonical no-FMA sum must be bit-exact too; scatter-add gradients (LDS /
 global float atomics, order not fixed) are held to 1e-5."""
+import copy
+
 import numpy as np
 import pytest
 import torch
@@ -727,6 +729,51 @@ def test_spectral_norm_split_equals_the_one_workgroup_kernel(hip):
             assert abs(sa - sb) <= 1e-5 * abs(sb), (R_, Cn, t)
     for x, y in zip(a[1] + a[2], b[1] + b[2]):
         assert torch.allclose(x, y, atol=2e-6)
+
+
+# ------------------------------------------------------------------ head: BatchNorm1d + LeakyReLU + dropout mask
+@pytest.mark.parametrize("B,C,masked", [(8, 256, True), (8, 64, False), (4, 256, True), (16, 300, True), (2, 64, False)])
+def test_head_bn_act_matches_oracle_and_torch_modules(hip, B, C, masked):
+    """tpg_head_bn_act_fwd / _bwd against the oracle's float64 restatement (1e-5) and against the modules they replace
+    -- nn.BatchNorm1d (training) -> nn.LeakyReLU -> product with a dropout mask -- outputs, running statistics, batch
+    counter and all three gradients."""
+    from tpgan_amd import ops
+    rng = np.random.default_rng(B * 1000 + C)
+    h = (rng.standard_normal((B, C)) * 2 + 0.5).astype(np.float32)
+    mask = ((rng.random((B, C)) > 0.3) / 0.7).astype(np.float32) if masked else None
+    bn = torch.nn.BatchNorm1d(C).cuda().train()
+    with torch.no_grad():
+        bn.weight.copy_(dev(rng.standard_normal(C).astype(np.float32)))
+        bn.bias.copy_(dev(rng.standard_normal(C).astype(np.float32)))
+        bn.running_mean.copy_(dev(rng.standard_normal(C).astype(np.float32)))
+        bn.running_var.copy_(dev(rng.random(C).astype(np.float32) + 0.5))
+    ref_bn = copy.deepcopy(bn)
+    rm0, rv0 = bn.running_mean.cpu().numpy().copy(), bn.running_var.cpu().numpy().copy()
+    x = dev(h).requires_grad_(True)
+    y = ops.head_bn_act(x, bn, 0.01, None if mask is None else dev(mask))
+    gy = dev(rng.standard_normal((B, C)).astype(np.float32))
+    gx, gg, gb = torch.autograd.grad(y, [x, bn.weight, bn.bias], gy)
+    # oracle
+    ry, rmean, rrstd, rrm, rrv = R.head_bn_act_fwd(h, ref_bn.weight.detach().cpu().numpy(), ref_bn.bias.detach().cpu().numpy(),
+                                                   rm0, rv0, 0.1, 1e-5, 0.01, mask)
+    assert np.abs(y.detach().cpu().numpy() - ry).max() <= 1e-5 * max(1.0, np.abs(ry).max())
+    assert np.abs(bn.running_mean.cpu().numpy() - rrm).max() <= 1e-6 and np.abs(bn.running_var.cpu().numpy() - rrv).max() <= 1e-5
+    assert int(bn.num_batches_tracked) == 1
+    rdh, rdg, rdb = R.head_bn_act_bwd(gy.cpu().numpy(), h, rmean, rrstd, ref_bn.weight.detach().cpu().numpy(),
+                                      ref_bn.bias.detach().cpu().numpy(), 0.01, mask)
+    for a, b in ((gx, rdh), (gg, rdg), (gb, rdb)):
+        assert np.abs(a.cpu().numpy() - b).max() <= 2e-5 * max(1.0, np.abs(b).max())
+    # the modules
+    x2 = dev(h).requires_grad_(True)
+    y2 = torch.nn.functional.leaky_relu(ref_bn(x2), 0.01)
+    if mask is not None:
+        y2 = y2 * dev(mask)
+    g2 = torch.autograd.grad(y2, [x2, ref_bn.weight, ref_bn.bias], gy)
+    assert torch.allclose(y, y2, rtol=1e-5, atol=1e-5)
+    for a, b in zip((gx, gg, gb), g2):
+        assert torch.allclose(a, b, rtol=1e-4, atol=2e-5 * float(b.abs().max() + 1))
+    assert torch.allclose(bn.running_mean, ref_bn.running_mean, atol=1e-6) and torch.allclose(bn.running_var, ref_bn.running_var, atol=1e-5)
+    assert int(ref_bn.num_batches_tracked) == 1
 
 
 # ------------------------------------------------------------------ fused cubic interpolation
