@@ -129,6 +129,13 @@ int tpg_gather_fwd_f32(const float *feat, const int32_t *idx, int B, int C, int 
 int tpg_gather_bwd_f32(const float *gout, const int32_t *idx, int B, int C, int N,
                        int S, float *gfeat, void *stream);
 
+/* gather_operation on channels-last rows (the layout this build keeps clouds in): out[b,s,:] = rows[b,idx[b,s],:];
+ * rows (B,N,C), idx (B,S) int32, out (B,S,C).  Same semantics as tpg_gather_fwd_f32 / _bwd_f32 on the transposed
+ * tensors (discriminator.py:131-137), without the two transpose copies around it. */
+int tpg_gather_rows_fwd_f32(const float *rows, const int32_t *idx, int B, int N, int S, int C, float *out, void *stream);
+int tpg_gather_rows_bwd_f32(const float *gout, const int32_t *idx, int B, int N, int S, int C, float *grows,
+                            void *stream);
+
 /* ball_query -- inside pointnet2_utils.QueryAndGroup, discriminator.py:190.
  * xyz (B,N,3), new_xyz (B,S,3) -> idx (B,S,nsample) int32. */
 int tpg_ball_query_f32(const float *xyz, const float *new_xyz, int B, int N, int S,

@@ -135,6 +135,15 @@ def gather_bwd(gout, idx, N):
     return g
 
 
+def gather_rows_fwd(rows, idx):
+    """tpg_gather_rows_fwd_f32 = gather_fwd on the transposed tensors."""
+    return np.ascontiguousarray(gather_fwd(np.ascontiguousarray(np.transpose(rows, (0, 2, 1))), idx).transpose(0, 2, 1))
+
+
+def gather_rows_bwd(gout, idx, N):
+    return np.ascontiguousarray(gather_bwd(np.ascontiguousarray(np.transpose(gout, (0, 2, 1))), idx, N).transpose(0, 2, 1))
+
+
 def ball_query(radius, nsample, xyz, new_xyz):
     xyz, new_xyz = _c(xyz, np.float32), _c(new_xyz, np.float32)
     B, N, _ = xyz.shape

@@ -55,6 +55,12 @@ class OracleBackend:
     def gather_bwd(self, gout, idx, N):
         return _t(R.gather_bwd(_np(gout), _np(idx), N))
 
+    def gather_rows_fwd(self, rows, idx):
+        return _t(R.gather_rows_fwd(_np(rows), _np(idx)))
+
+    def gather_rows_bwd(self, gout, idx, N):
+        return _t(R.gather_rows_bwd(_np(gout), _np(idx), N))
+
     def ball_query(self, radius, nsample, xyz, new_xyz):
         return _t(R.ball_query(radius, nsample, _np(xyz), _np(new_xyz)))
 

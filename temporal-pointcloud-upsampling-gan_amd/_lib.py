@@ -36,6 +36,8 @@ SIGNATURES = {
     "tpg_three_nn_f32": [_P, _P, _I, _I, _I, _P, _P, _P],
     "tpg_three_interp_fwd_f32": [_P, _P, _P, _I, _I, _I, _I, _P, _P],
     "tpg_three_interp_bwd_f32": [_P, _P, _P, _I, _I, _I, _I, _P, _P],
+    "tpg_gather_rows_fwd_f32": [_P, _P, _I, _I, _I, _I, _P, _P],
+    "tpg_gather_rows_bwd_f32": [_P, _P, _I, _I, _I, _I, _P, _P],
     "tpg_rowcombine_fwd": [_P, _P, _P, _I, _I, _I, _I, _I, _I, _I, _I, _F, _P, _P],
     "tpg_invert_index": [_P, _I, _I, _I, _P, _P, _P, _P],
     "tpg_rowcombine_bwd": [_P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _I, _I, _F, _P, _P, _P],

@@ -183,6 +183,33 @@ __global__ __launch_bounds__(256) void gather_bwd_kernel(const float *__restrict
     atomicAdd(gfeat + ((size_t)b * C + c) * N + n, gout[((size_t)b * C + c) * S + s]);
 }
 
+// the same gather on channels-last rows: out[b,s,:] = rows[b,idx[b,s],:] (C small: point coordinates).  The rows path
+// of the set-abstraction levels keeps clouds as (B,N,3); through the planes form above a centre gather was transpose
+// copy -> gather -> transpose copy, three launches each way, twice per level and pass.
+__global__ __launch_bounds__(256) void gather_rows_fwd_kernel(const float *__restrict__ rows,
+                                                              const int32_t *__restrict__ idx, int N, int S, int C,
+                                                              float *__restrict__ out, long long total) {
+    const long long t = (long long)blockIdx.x * 256 + threadIdx.x;
+    if (t >= total) return;
+    const long long bs = t / C;
+    const int c = (int)(t - bs * C);
+    const long long b = bs / S;
+    const int n = tpg_clamp_idx(idx[bs], N);
+    out[t] = rows[((size_t)b * N + n) * C + c];
+}
+
+__global__ __launch_bounds__(256) void gather_rows_bwd_kernel(const float *__restrict__ gout,
+                                                              const int32_t *__restrict__ idx, int N, int S, int C,
+                                                              float *__restrict__ grows, long long total) {
+    const long long t = (long long)blockIdx.x * 256 + threadIdx.x;
+    if (t >= total) return;
+    const long long bs = t / C;
+    const int c = (int)(t - bs * C);
+    const long long b = bs / S;
+    const int n = tpg_clamp_idx(idx[bs], N);
+    atomicAdd(grows + ((size_t)b * N + n) * C + c, gout[t]);
+}
+
 bool grid_ok(long long x, long long y, long long z) {
     return x > 0 && y > 0 && z > 0 && x <= 0x7fffffffLL && y <= 65535 && z <= 65535;
 }
@@ -284,6 +311,37 @@ extern "C" int tpg_gather_bwd_f32(const float *gout, const int32_t *idx, int B, 
     if (!grid_ok(gx, C, B)) return TPG_ERR_ARG;
     hipLaunchKernelGGL(gather_bwd_kernel, dim3((unsigned)gx, (unsigned)C, (unsigned)B), dim3(256), 0, st,
                        gout, idx, C, N, S, gfeat);
+    TPG_RETURN_IF_LAUNCH_FAILED();
+    return TPG_OK;
+}
+
+extern "C" int tpg_gather_rows_fwd_f32(const float *rows, const int32_t *idx, int B, int N, int S, int C, float *out,
+                                       void *stream) {
+    if (B < 0 || C < 0 || N <= 0 || S < 0) return TPG_ERR_ARG;
+    const long long total = (long long)B * S * C;
+    if (total == 0) return TPG_OK;
+    if (!rows || !idx || !out) return TPG_ERR_ARG;
+    const long long gx = (total + 255) / 256;
+    if (!grid_ok(gx, 1, 1)) return TPG_ERR_ARG;
+    hipLaunchKernelGGL(gather_rows_fwd_kernel, dim3((unsigned)gx), dim3(256), 0, tpg_stream(stream), rows, idx, N, S, C, out,
+                       total);
+    TPG_RETURN_IF_LAUNCH_FAILED();
+    return TPG_OK;
+}
+
+extern "C" int tpg_gather_rows_bwd_f32(const float *gout, const int32_t *idx, int B, int N, int S, int C, float *grows,
+                                       void *stream) {
+    if (B < 0 || C < 0 || N <= 0 || S < 0) return TPG_ERR_ARG;
+    if (B == 0 || C == 0) return TPG_OK;
+    if (!grows) return TPG_ERR_ARG;
+    hipStream_t st = tpg_stream(stream);
+    if (hipMemsetAsync(grows, 0, sizeof(float) * (size_t)B * N * C, st) != hipSuccess) return TPG_ERR_LAUNCH;
+    const long long total = (long long)B * S * C;
+    if (total == 0) return TPG_OK;
+    if (!gout || !idx) return TPG_ERR_ARG;
+    const long long gx = (total + 255) / 256;
+    if (!grid_ok(gx, 1, 1)) return TPG_ERR_ARG;
+    hipLaunchKernelGGL(gather_rows_bwd_kernel, dim3((unsigned)gx), dim3(256), 0, st, gout, idx, N, S, C, grows, total);
     TPG_RETURN_IF_LAUNCH_FAILED();
     return TPG_OK;
 }

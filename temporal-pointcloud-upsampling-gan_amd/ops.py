@@ -283,6 +283,21 @@ class HipBackend:
                    _ptr(gout), _ptr(idx), B, Cc, N, S, _ptr(g))
         return g
 
+    def gather_rows_fwd(self, rows, idx):
+        B, N, Cc = rows.shape
+        S = idx.shape[1]
+        out = torch.empty((B, S, Cc), dtype=torch.float32, device=rows.device)
+        self._call("tpg_gather_rows_fwd_f32", "gather_fwd", 4 * B * S * (2 * Cc + 1), rows,
+                   _ptr(rows), _ptr(idx), B, N, S, Cc, _ptr(out))
+        return out
+
+    def gather_rows_bwd(self, gout, idx, N):
+        B, S, Cc = gout.shape
+        g = torch.empty((B, N, Cc), dtype=torch.float32, device=gout.device)
+        self._call("tpg_gather_rows_bwd_f32", "gather_bwd", 4 * B * (Cc * N + S + 2 * Cc * S), gout,
+                   _ptr(gout), _ptr(idx), B, N, S, Cc, _ptr(g))
+        return g
+
     def ball_query(self, radius, nsample, xyz, new_xyz):
         B, N, _ = xyz.shape
         S = new_xyz.shape[1]
@@ -923,6 +938,28 @@ class _Gather(torch.autograd.Function):
 def gather_operation(features, idx):
     """(B,C,N),(B,S) int32 -> (B,C,S).  Reference call site discriminator.py:131-137."""
     return _Gather.apply(features, idx)
+
+
+class _GatherRows(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, rows, idx):
+        _check_float(rows, "rows", 3)
+        _check_int(idx, "idx", 2)
+        _same_device(rows, idx)
+        ctx.save_for_backward(idx)
+        ctx.N = rows.shape[1]
+        return backend_for(rows).gather_rows_fwd(rows, idx)
+
+    @staticmethod
+    def backward(ctx, grad_out):
+        (idx,) = ctx.saved_tensors
+        return backend_for(grad_out).gather_rows_bwd(grad_out.contiguous().float(), idx, ctx.N), None
+
+
+def gather_rows(rows, idx):
+    """(B,N,C) rows, (B,S) int32 -> (B,S,C): gather_operation (discriminator.py:131-137) in the layout the rows path
+    keeps its clouds in -- one launch each way instead of transpose copy + gather + transpose copy."""
+    return _GatherRows.apply(rows, idx)
 
 
 def ball_query(radius, nsample, xyz, new_xyz):

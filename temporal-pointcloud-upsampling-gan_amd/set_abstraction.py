@@ -403,7 +403,7 @@ class _PointnetSAModuleBase(nn.Module):
         prefix: see `sample_centres` (pass the same list to every level of a chain, [None] at the first)."""
         xyz = xyz.detach().float().contiguous()
         centres = self.sample_centres(xyz, prefix)
-        new_xyz = ops.gather_operation(xyz.transpose(1, 2).contiguous(), centres).transpose(1, 2).contiguous()
+        new_xyz = _gather_centres(xyz, centres)
         g = self.groupers[0]
         idx = _sources(ops.ball_query(g.radius, g.nsample, xyz, new_xyz), xyz.shape[1])
         if inverse and rows_first():
@@ -439,8 +439,7 @@ class _PointnetSAModuleBase(nn.Module):
                 centres, pidx = plan
             else:
                 centres = self.sample_centres(xyz)
-            new_xyz = ops.gather_operation(xyz.transpose(1, 2).contiguous(), centres)
-            new_xyz = new_xyz.transpose(1, 2).contiguous()
+            new_xyz = _gather_centres(xyz, centres)
         else:
             new_xyz = None
         outs = []
@@ -487,7 +486,7 @@ class _PointnetSAModuleBase(nn.Module):
         xyz = xyz.float().contiguous()
         NB, N, _ = xyz.shape
         centres = plan[0] if plan is not None else self.sample_centres(xyz)
-        new_xyz = ops.gather_operation(xyz.transpose(1, 2).contiguous(), centres).transpose(1, 2).contiguous()
+        new_xyz = _gather_centres(xyz, centres)
         idx = plan[1] if plan is not None else ops.ball_query(grouper.radius, grouper.nsample, xyz, new_xyz)
         S = new_xyz.shape[1]
         conv = mlp[0]
@@ -775,6 +774,14 @@ def _head_fp32(fc_layers, x):
                 x = m(x)
             i += 1
         return x
+
+
+def _gather_centres(xyz, centres):
+    """Coordinates of the sampled centres, (B,S,3) rows: gather_operation (discriminator.py:131-137) -- on the rows path as
+    one launch on the rows themselves, in the reference's order through the (B,3,N) planes it uses."""
+    if rows_first():
+        return ops.gather_rows(xyz.contiguous(), centres)
+    return ops.gather_operation(xyz.transpose(1, 2).contiguous(), centres).transpose(1, 2).contiguous()
 
 
 def _sources(idx, n_src):

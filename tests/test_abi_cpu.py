@@ -117,6 +117,11 @@ def test_new_entries_reject_bad_arguments_before_any_launch(hip_lib):
     assert hip_lib.tpg_spectral_norm_multi_fwd_split(p, p, 0, 64, p, p, 8, 1e-12, None) == 0
     assert hip_lib.tpg_spectral_norm_multi_fwd_split(p, p, 1, 577, p, p, 8, 1e-12, None) == -3
     assert hip_lib.tpg_spectral_norm_split_rows() == 32 and hip_lib.tpg_spectral_norm_split_max_cn() == 576
+    # rows gather
+    assert hip_lib.tpg_gather_rows_fwd_f32(p, p, 1, 0, 4, 3, p, None) == -1
+    assert hip_lib.tpg_gather_rows_fwd_f32(None, p, 1, 8, 4, 3, p, None) == -1
+    assert hip_lib.tpg_gather_rows_fwd_f32(p, p, 0, 8, 4, 3, p, None) == 0
+    assert hip_lib.tpg_gather_rows_bwd_f32(p, p, 1, 8, 4, 3, None, None) == -1
     # head BatchNorm1d + LeakyReLU + mask: one row is an error (as nn.BatchNorm1d in training mode), outputs required
     assert hip_lib.tpg_head_bn_act_fwd(p, 1, 8, p, p, p, p, None, 0.1, 1e-5, 0.01, None, p, p, p, None) == -1
     assert hip_lib.tpg_head_bn_act_fwd(p, 4, 8, p, p, p, p, None, 0.1, 1e-5, 0.01, None, None, p, p, None) == -1

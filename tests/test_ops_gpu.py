@@ -388,6 +388,29 @@ def test_full_size_properties_cfg2(hip):
     assert torch.equal(i1, torch.arange(4096, device="cuda").expand(8, -1))
 
 
+@pytest.mark.parametrize("B,N,S,C", [(3, 4096, 1024, 3), (2, 512, 128, 3), (1, 100, 100, 6), (2, 64, 7, 1)])
+def test_gather_rows_equals_gather_operation_on_the_transposed_tensors(hip, B, N, S, C):
+    """tpg_gather_rows_*: bit-exact against the oracle (a pure copy; sums of the backward meet only on repeated centres)
+    and against tpg_gather_*_f32 on the (B,C,N) planes."""
+    from tpgan_amd import ops
+    rng = np.random.default_rng(N + S)
+    rows = rng.standard_normal((B, N, C)).astype(np.float32)
+    idx = np.stack([rng.permutation(N)[:S] for _ in range(B)]).astype(np.int32)
+    idx[0, :3] = idx[0, 3]                       # a centre picked several times
+    x = dev(rows).requires_grad_(True)
+    out = ops.gather_rows(x, dev(idx))
+    assert np.array_equal(out.detach().cpu().numpy(), R.gather_rows_fwd(rows, idx))
+    g = rng.standard_normal((B, S, C)).astype(np.float32)
+    (gx,) = torch.autograd.grad(out, x, dev(g))
+    ref = R.gather_rows_bwd(g, idx, N)
+    assert np.abs(gx.cpu().numpy() - ref).max() <= 1e-6 * max(1.0, np.abs(ref).max())
+    x2 = dev(rows).requires_grad_(True)
+    out2 = ops.gather_operation(x2.transpose(1, 2).contiguous(), dev(idx)).transpose(1, 2)
+    assert torch.equal(out, out2)
+    (gx2,) = torch.autograd.grad(out2, x2, dev(g))
+    assert torch.allclose(gx, gx2, atol=1e-6)
+
+
 # ------------------------------------------------------------------ row combine (channels-last)
 def _bf16_round(a):
     return torch.from_numpy(np.ascontiguousarray(a)).bfloat16().float().numpy()
