@@ -201,6 +201,71 @@ def test_fps_bit_exact(hip, B, N, m):
     assert np.array_equal(idx.cpu().numpy(), R.fps(x, m))
 
 
+@pytest.mark.parametrize("case", ["clusters", "line", "one_point", "few_distinct", "none_eligible", "ragged_8192",
+                                  "ragged_12289", "smallest_pruned", "start_all_eligible", "far_coordinates", "clusters_16384", "few_distinct_9000"])
+def test_fps_pruned_rounds_bit_exact(hip, case):
+    """The pruned rounds of csrc/fps.hip (Morton-ordered tiles, box bounds, tile records; the kernel takes clouds of
+    8193..16384 points and >= 128 picks -- the smaller cases here keep the dense kernel honest on the same shapes)
+    against the oracle, bit for bit, on the shapes that stress the pruning: far-apart clusters (most
+    tiles skipped from the first rounds on), degenerate extents, ties everywhere, no eligible point, clouds that do not
+    fill the last tiles, picks by original index when tiles hold points out of index order."""
+    rng = np.random.default_rng(len(case))
+    start, skip = None, True
+    if case == "clusters":
+        x = np.concatenate([fluid(rng, 2, 2048) * 0.05 + 0.4, fluid(rng, 2, 2048) * 0.05 - 0.4], axis=1)
+        x = x[:, rng.permutation(4096)]
+        m = 1024
+    elif case == "line":
+        x = np.zeros((2, 9000, 3), np.float32)
+        x[..., 0] = rng.uniform(0.1, 1.0, (2, 9000))
+        x[..., 1] = 0.3
+        m = 512
+    elif case == "one_point":
+        x = np.full((1, 9000, 3), 0.25, np.float32)
+        m = 200
+    elif case == "few_distinct":
+        few = fluid(rng, 1, 40)[0]
+        x = few[rng.integers(0, 40, (2, 5000))]
+        m = 300
+    elif case == "none_eligible":
+        x = np.full((2, 10000, 3), 0.01, np.float32)
+        x[0] = fluid(rng, 1, 10000)[0]
+        m = 256
+    elif case == "ragged_8192":
+        x = fluid(rng, 2, 8190)
+        m = 2048
+    elif case == "ragged_12289":
+        x = fluid(rng, 1, 12289)
+        x[0, 5] = 0.0
+        m = 700
+    elif case == "smallest_pruned":
+        x = fluid(rng, 3, 2049)
+        m = 128
+    elif case == "start_all_eligible":
+        x = (rng.standard_normal((2, 9216, 3)) * 0.3).astype(np.float32)
+        x[0, 7] = 0.0
+        start, skip, m = rng.integers(0, 9216, 2).astype(np.int32), False, 1152
+    elif case == "clusters_16384":
+        x = np.concatenate([fluid(rng, 1, 8192) * 0.05 + 0.4, fluid(rng, 1, 8192) * 0.05 - 0.4], axis=1)
+        x = x[:, rng.permutation(16384)]
+        m = 2048
+    elif case == "few_distinct_9000":
+        few = fluid(rng, 1, 40)[0]
+        x = few[rng.integers(0, 40, (2, 9000))]
+        m = 300
+    else:
+        x = fluid(rng, 2, 9000) + np.float32(2.0e5)          # box bounds beyond the 1e10 start value of the distances
+        m = 300
+    x = np.ascontiguousarray(x, np.float32)
+    if start is None:
+        got = hip.fps(dev(x), m).cpu().numpy()
+        want = R.fps(x, m)
+    else:
+        got = hip.fps(dev(x), m, dev(start), skip).cpu().numpy()
+        want = R.fps_start(x, m, start, skip_origin=skip)
+    assert np.array_equal(got, want), (case, np.argwhere(got != want)[:5])
+
+
 def test_fps_all_points_inside_origin_ball(hip):
     x = np.full((2, 300, 3), 0.01, np.float32)
     assert np.array_equal(hip.fps(dev(x), 16).cpu().numpy(), R.fps(x, 16))
