@@ -22,9 +22,9 @@ from tpgan_amd.gan_step_graph import GraphedFluidStep                    # noqa:
 def main():
     dev = torch.device("cuda", 0)
     np.random.seed(0)
-    G, Ds, Dt, opts = bench.build(dev, capturable=True)
-    clips = [fluid_clip(8, 4096, 8, 3, seed=s, device=dev) for s in range(4)]
-    step = GraphedFluidStep(G, Ds, Dt, opts, bench.OPT, clips[0][0], clips[0][1], 1.0, torch.bfloat16, None)
+    from tpgan_amd import configs
+    clips = [configs.make_clip("cfg2", seed=s, device=dev) for s in range(4)]
+    step = configs.graphed_step("cfg2", configs.build_models("cfg2", dev, capturable=True), clips[0], amp_dtype=torch.bfloat16)
     n = 40
     for i in range(3):
         step(*clips[i % 4], 12)
