@@ -165,6 +165,7 @@ class GraphedFluidStep:
             from .srnet import set_aux_stream
             set_aux_stream(sr_net, self.aux)
         self.use_plans = True
+        self.defer_inverses = os.environ.get("TPGAN_DEFER_INVERSES", "1") != "0"
         self.wgrad_side = os.environ.get("TPGAN_WGRAD_SIDE", "0") != "0"    # measured: 13.1 -> 14.5 ms with it (a cross-stream edge per weight costs ~40 us): off
         self._keep = {}
         self._graphs = None
@@ -230,9 +231,30 @@ class GraphedFluidStep:
         (k["fakes"], plan_ft, upd_t), join_ft = run_index_plan(both_t, self.sides[0])
         # fake and real batch run as segments of ONE discriminator pass: one plan for both, put
         # together after the generator step's plan is out (same stream as the real batch's plan)
-        k["plan_s"], _ = run_index_plan(lambda: Ds.merge_plans([upd_s, k["plan_true_s"]]), self.sides[1])
-        k["plan_t"], _ = run_index_plan(lambda: Dt.merge_plans([upd_t, k["plan_true_t"]]), self.sides[0])
+        # (their inverted indices -- read by the backward only -- are built BEHIND the event the update's forward waits
+        # for: `_update_plan`; TPGAN_DEFER_INVERSES=0 for the A/B: 12.52 -> 12.32 ms at cfg2.  The same for the generator
+        # step's own plans measured SLOWER, 12.62 -> 12.84: its backward then waits for the side streams once more)
+        k["plan_s"], k["join_plan_s"] = self._update_plan(lambda: Ds.merge_plans([upd_s, k["plan_true_s"]]), self.sides[1])
+        k["plan_t"], k["join_plan_t"] = self._update_plan(lambda: Dt.merge_plans([upd_t, k["plan_true_t"]]), self.sides[0])
         return join_fs, join_ft, plan_fs, plan_ft
+
+    def _update_plan(self, merge, side):
+        """The merged (fake + real) index plan of a discriminator update on `side`: the lists first, an event for the
+        update's forward, then the lists' inverted indices (a row gather's backward is their only reader; the update
+        waits for the whole side stream before its backward starts).  -> plan, join (to call on the update's stream)."""
+        from . import ops
+        if not self.defer_inverses:
+            plan, _ = run_index_plan(merge, side)
+            return plan, (lambda: torch.cuda.current_stream(self.dev).wait_stream(side))
+
+        def lists_only():
+            with ops.deferred_inverses() as pending:
+                plan = merge()
+            return plan, list(pending)
+        (plan, pending), join = run_index_plan(lists_only, side)
+        with torch.cuda.stream(side):
+            ops.run_inverses(pending)
+        return plan, join
 
     def _prepare_sn_in_gap(self):
         """Called (discriminators frozen) right before the generator step's stream waits for the
@@ -373,9 +395,15 @@ class GraphedFluidStep:
         main = torch.cuda.current_stream(self.dev)
         if update_D:
             self.branch.wait_stream(main)
-            self.branch.wait_stream(self.sides[1])      # the spatial update's clouds and index plan
             self.branch2.wait_stream(main)
-            self.branch2.wait_stream(self.sides[0])     # the temporal update's
+            if self.use_plans:                          # the updates' clouds and index lists (their inverted indices: below)
+                with torch.cuda.stream(self.branch):
+                    k["join_plan_s"]()
+                with torch.cuda.stream(self.branch2):
+                    k["join_plan_t"]()
+            else:
+                self.branch.wait_stream(self.sides[1])
+                self.branch2.wait_stream(self.sides[0])
             # issue order = the eager step's (and the reference's, train_step_final.py:171-214): the
             # temporal update first.  The streams decide what runs where; the ISSUE order decides
             # which Philox offsets the heads' dropout draws get inside a captured graph.
@@ -387,6 +415,7 @@ class GraphedFluidStep:
                         fake, true = dis.forward_passes(passes, *kw.get("args", ()), plan=plan)
                     loss = (0.5 * ((true.float() - lab[0]) ** 2 + (fake.float() - lab[1]) ** 2)).mean()
                     optim.zero_grad(set_to_none=True)
+                    branch.wait_stream(kw["side"])          # the plan's inverted indices (built behind its lists)
                     loss.backward()
                     k[key] = loss.detach()
                     k[key].record_stream(main)
@@ -394,9 +423,10 @@ class GraphedFluidStep:
             if skip:
                 k["tempo_dis_loss"] = k["spatial_dis_loss"] = torch.zeros((), device=self.dev)
             if "t" not in skip:
-                update(self.Dt, self.ot, self.branch2, [k["fakes"], k["trues"]], k["plan_t"], "tempo_dis_loss", args=(self.opt.R,))
+                update(self.Dt, self.ot, self.branch2, [k["fakes"], k["trues"]], k["plan_t"], "tempo_dis_loss", args=(self.opt.R,),
+                       side=self.sides[0])
             if "s" not in skip:
-                update(self.Ds, self.os, self.branch, [k["fake_s"], k["true_s"]], k["plan_s"], "spatial_dis_loss")
+                update(self.Ds, self.os, self.branch, [k["fake_s"], k["true_s"]], k["plan_s"], "spatial_dis_loss", side=self.sides[1])
         else:
             k["tempo_dis_loss"] = torch.zeros((), device=self.dev)
             k["spatial_dis_loss"] = torch.zeros((), device=self.dev)

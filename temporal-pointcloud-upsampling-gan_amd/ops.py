@@ -1241,12 +1241,40 @@ def row_combine(U, QE, idx, mode, slope=0.2, out_dtype=None):
     return _RowCombine.apply(U, QE, idx, mode, float(slope), out_dtype, inverse)
 
 
+_DEFERRED_INVERSES = []        # stack of lists: inside `deferred_inverses()` attach_inverse only notes its arguments
+
+
+class deferred_inverses:
+    """with deferred_inverses() as pending: ... -- `attach_inverse` calls inside launch nothing; `run_inverses(pending)`
+    launches them later (on the stream current then) and hangs the results on the index tensors.  The inverted index is
+    read by a row gather's BACKWARD only, so an index plan can hand its lists to the forward first and build the
+    inverses behind that (gan_step_graph: ~150 us earlier start of a discriminator update)."""
+
+    def __enter__(self):
+        self.pending = []
+        _DEFERRED_INVERSES.append(self.pending)
+        return self.pending
+
+    def __exit__(self, *exc):
+        _DEFERRED_INVERSES.pop()
+        return False
+
+
+def run_inverses(pending):
+    for idx, N in pending:
+        attach_inverse(idx, N)
+    del pending[:]
+
+
 def attach_inverse(idx, N):
     """Prepare the inverted index of a neighbour list idx (B,S,K) int32 into N source rows NOW
     (on the current stream) and hang it on the tensor: `row_combine` hands it to its backward,
     which then skips its own tpg_invert_index launch.  Index-only work like FPS and the ball
     query, so an index plan can take it off the critical path.  Returns idx."""
     _need(idx.dtype == torch.int32 and idx.dim() == 3 and idx.is_contiguous(), "idx must be contiguous (B,S,K) int32")
+    if _DEFERRED_INVERSES:
+        _DEFERRED_INVERSES[-1].append((idx, int(N)))
+        return idx
     be = backend_for(idx)
     if hasattr(be, "invert_index"):
         offs, lst = be.invert_index(idx, int(N))
