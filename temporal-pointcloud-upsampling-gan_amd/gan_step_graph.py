@@ -318,20 +318,21 @@ class GraphedFluidStep:
             stacked = torch.cat([low[f] for f in order], 0)
             edge_all, mask_all = G.body(stacked, stacked)
         nT = len(order)                       # unbind: ONE stack in the backward instead of per-slice fills
-        edges = edge_all.reshape(nT, self.B, *edge_all.shape[1:]).unbind(0)
-        masks = mask_all.reshape(nT, self.B, *mask_all.shape[1:]).unbind(0)
-        edge, mask = edges[0], masks[0]
-        pred_c, padded_c, keep_c = G.expand_pos_static(low[1], edge, mask)
+        mask = mask_all[:self.B]              # (the centre frame's: the only one a loss reads)
+        # the position expansion of all T frames in one call on the stacked clouds (elementwise: the same values as T calls,
+        # a third of the launches in front of the fork of the fake clouds' index plans); `keep_all` = every frame kept all
+        pred_all, padded_all, keep_all = G.expand_pos_static(stacked, edge_all, mask_all)       # (12.20 -> 12.08 ms, same-box A/B)
+        preds = pred_all.reshape(nT, self.B, *pred_all.shape[1:]).unbind(0)
+        paddeds = padded_all.reshape(nT, self.B, *padded_all.shape[1:]).unbind(0)
+        pred_c, padded_c = preds[0], paddeds[0]
         fake_s_in = padded_c.index_select(1, self.perm_c).float()
-        viol = ~keep_c
+        viol = ~keep_all
         with _frozen(Ds, Dt), _autocast(self.amp, self.dev):
             pred_lst = [None] * self.T
             pred_lst[1] = padded_c
             for i, f in enumerate(others):
-                _, padded, keep = G.expand_pos_static(low[f], edges[i + 1], masks[i + 1])
-                viol = viol | ~keep
-                pred_lst[f] = padded.index_select(1, self.perm_f[i])
-                last_padded = padded
+                pred_lst[f] = paddeds[i + 1].index_select(1, self.perm_f[i])
+            last_padded = paddeds[-1]
             fake_t_in = [p.float() for p in pred_lst]
         join_fs, join_ft, plan_fs, plan_ft = self._fake_plans(
             update_D, fake_s_in, fake_t_in,
