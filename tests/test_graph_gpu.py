@@ -222,6 +222,37 @@ def test_replay_is_bitwise_its_own_body_launched_eagerly(dropout):
     assert not bad, bad
 
 
+def test_inverted_indices_behind_their_lists_change_nothing(monkeypatch):
+    """The update plans' inverted indices are built BEHIND the event their forward waits for (GraphedFluidStep._update_plan,
+    ops.deferred_inverses): the same index, read by the backward only, so a replayed step with the deferral equals the
+    step without it bit for bit in the discriminators (losses, parameters, BatchNorm / spectral-norm state); a missing
+    wait in front of the backward would show as stale or garbage gradients.  The generator is held to 1e-6 like in
+    test_replay_is_bitwise_its_own_body_launched_eagerly (library GEMM split-K)."""
+    from tpgan_amd.gan_step_graph import GraphedFluidStep
+    from tpgan_amd.synthetic import fluid_clip
+    dev = torch.device("cuda", 0)
+    A = _build(dev)
+    Bm = copy.deepcopy(A)
+    oa, ob = _optims(*A), _optims(*Bm)
+    clips = [fluid_clip(4, 1024, 8, 3, seed=s, device=dev) for s in (1, 2)]
+    monkeypatch.setenv("TPGAN_DEFER_INVERSES", "1")
+    sa = GraphedFluidStep(A[0], A[1], A[2], oa, OPT, clips[0][0], clips[0][1], 1.0, None, None)
+    monkeypatch.setenv("TPGAN_DEFER_INVERSES", "0")
+    sb = GraphedFluidStep(Bm[0], Bm[1], Bm[2], ob, OPT, clips[0][0], clips[0][1], 1.0, None, None)
+    assert sa.defer_inverses and not sb.defer_inverses
+    init_g = [p.detach().clone() for p in A[0].parameters()]
+    np.random.seed(7); torch.manual_seed(7)
+    la = sa(clips[1][0], clips[1][1], 12)
+    np.random.seed(7); torch.manual_seed(7)
+    lb = sb(clips[1][0], clips[1][1], 12)
+    assert la == lb, (la, lb)
+    for ma, mb in ((A[1], Bm[1]), (A[2], Bm[2])):
+        for (k, va), vb in zip(ma.state_dict().items(), mb.state_dict().values()):
+            assert torch.equal(va, vb), k
+    da, db = _delta(A[0], init_g), _delta(Bm[0], init_g)
+    assert float((da - db).norm() / da.norm()) <= 1e-6
+
+
 def test_step_sensitivity_explains_the_replay_vs_eager_gap():
     """Why `test_graph_replay_equals_eager` holds the parameter deltas to 2e-2 and not to 1e-6.
 
